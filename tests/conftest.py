@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import midd_loader  # noqa: E402
+
+midd_loader.load()
+
+REFERENCE_DIR = "/root/reference/Backend"
+HAVE_REFERENCE = os.path.isdir(REFERENCE_DIR)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    skip_ref = pytest.mark.skip(reason="/root/reference not present (GPU box)")
+    for item in items:
+        if "reference" in item.keywords and not HAVE_REFERENCE:
+            item.add_marker(skip_ref)
+
+
+@pytest.fixture(scope="session")
+def reference_module():
+    """Imports the reference's DDIM module in-process (SURVEY.md App. B recipe)."""
+    if not HAVE_REFERENCE:
+        pytest.skip("/root/reference not present")
+    from tests.golden.ref_import import import_reference
+    return import_reference()
