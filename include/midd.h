@@ -1,0 +1,133 @@
+/*
+ * midd.h — C ABI of libmidd.so, the MI355X (gfx950) native implementation of the
+ * reverse-diffusion sampler path.
+ *
+ * The reference has no FFI/operator interface for this path: its boundary is two Python
+ * classes, UNetDiffusion / DiffusionDenoiser (/root/reference/Backend/DDIM/DDIMModel.py:169-289),
+ * imported by name at /root/reference/Backend/run.py:13.  Every entry point below cites the
+ * reference interface it replaces; the ctypes binding a maintainer adds on the reference
+ * side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers and sizes only; no torch / C++ types.
+ *   - every function returns 0 on success or a negative MI_E* code; the message is
+ *     available from mi_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - image / workspace pointers are DEVICE pointers on the current HIP device; weight,
+ *     schedule and timestep-list pointers are HOST pointers.
+ *   - forward/denoise allocate nothing: the caller supplies the workspace (size from
+ *     mi_workspace_bytes) and a stream (void* = hipStream_t, NULL = default stream).
+ *     They are asynchronous with respect to the host; the caller synchronises.
+ *   - a plan is immutable after mi_unet_finalize and may be shared by threads; concurrent
+ *     calls must use distinct workspaces (run.py:85-91 calls the sampler from a worker thread).
+ *   - images are fp32, contiguous [B, in_channels, H, W] exactly as the reference passes
+ *     them (DDIMModel.py:219, :269); H and W must be multiples of 2^(levels-1) (8).
+ */
+#ifndef MIDD_H
+#define MIDD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK            0
+#define MI_EINVAL       -1   /* bad argument / unsupported shape or topology */
+#define MI_ESTATE       -2   /* call order (e.g. forward before finalize, missing weight) */
+#define MI_EHIP         -3   /* a HIP runtime call or kernel launch failed */
+#define MI_ENOMEM       -4   /* workspace too small */
+
+#define MI_MAX_LEVELS    8
+
+#define MI_VARIANT_DDIM  0   /* Backend/DDIM/DDIMModel.py  */
+#define MI_VARIANT_CDDPM 1   /* Backend/cddpm/cddpmModels.py */
+
+/* sampler flags for mi_denoise */
+#define MI_CLAMP_EPS     1   /* clamp(eps,-5,5) before the update: DDIMModel.py:278 (absent in cddpm) */
+
+typedef struct mi_plan mi_plan;
+
+/* Constructor arguments of UNetDiffusion.__init__ (DDIMModel.py:169-170). */
+typedef struct mi_unet_cfg {
+    int32_t in_channels;                         /* 1 */
+    int32_t model_channels;                      /* 48; must be a multiple of 16 */
+    int32_t num_levels;                          /* len(channel_mult) = 4 */
+    int32_t channel_mult[MI_MAX_LEVELS];         /* (1,2,3,4) */
+    int32_t num_res_blocks;                      /* 2 */
+    int32_t num_attention_levels;                /* len(attention_resolutions) = 1 */
+    int32_t attention_levels[MI_MAX_LEVELS];     /* (3,) — level indices */
+    int32_t time_emb_dim;                        /* 192 */
+    int32_t variant;                             /* MI_VARIANT_* */
+} mi_unet_cfg;
+
+/* Replaces UNetDiffusion.__init__ (DDIMModel.py:169-217): derives the module lists
+ * (downs / mid / ups) and the expected state-dict entries. */
+int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out);
+
+/* Replaces model.load_state_dict(ckpt['model_state_dict']) (run.py:37-39): called once per
+ * state-dict entry with the reference's key name (e.g. "downs.3.block1.2.weight",
+ * "ups.6.weight" [Cin,Cout,4,4]).  `data` is a HOST pointer to contiguous fp32. */
+int mi_unet_load_weights(mi_plan* plan, const char* key, const float* data,
+                         const int64_t* shape, int ndim);
+
+/* Number of state-dict entries the plan expects / the i-th expected key (for the host
+ * shim's strict-load check). */
+int mi_unet_num_weights(const mi_plan* plan);
+const char* mi_unet_weight_name(const mi_plan* plan, int index);
+
+/* Repacks all weights into kernel layouts on the device (MFMA fragment order, folded
+ * ConvTranspose+resample 3x3 — DDIMModel.py:211,241-242), and precomputes the timestep
+ * table: time_mlp (DDIMModel.py:99-106,173-178) followed by every ResidualBlock's
+ * Linear(SiLU(.)) (DDIMModel.py:111-114,130) for t in [0, time_rows).
+ * May be called again after further mi_unet_load_weights calls (re-uploads). */
+int mi_unet_finalize(mi_plan* plan, int time_rows);
+
+/* Bytes of device workspace one forward/denoise call needs at this shape. */
+size_t mi_workspace_bytes(mi_plan* plan, int B, int H, int W);
+
+/* Replaces UNetDiffusion.forward(x, condition, t) (DDIMModel.py:219-248).
+ * x, condition: device fp32 [B,in_channels,H,W]; t: HOST int32[B] (the reference takes an
+ * int64 tensor; the sampler always passes B equal values, DDIMModel.py:275);
+ * eps: device fp32 [B,in_channels,H,W]. */
+int mi_unet_forward(mi_plan* plan, const float* x, const float* condition, const int32_t* t,
+                    float* eps, int B, int H, int W,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces DiffusionDenoiser.denoise(noisy_img, inference_steps) (DDIMModel.py:268-289; cddpm:
+ * cddpmModels.py:281-308).  The iteration list and the schedule tables are passed in by the
+ * host shim, which computes them exactly as the reference does (DDIMModel.py:255-257,272-274).
+ *   noisy      device fp32 [B,C,H,W]; never written (DDIMModel.py:271 clones it)
+ *   x_out      device fp32 [B,C,H,W]; receives x after the last iteration
+ *   t_list     HOST int32[n_iters] timesteps in execution order (each < noise_steps <= time_rows)
+ *   beta/alpha/alpha_hat  HOST fp32[noise_steps]
+ *   step_noise device fp32 [n_iters,B,C,H,W] or NULL: the already 0.5-scaled Gaussian noise of
+ *              the cddpm variant (cddpmModels.py:297-302); entry i is ignored when t_list[i]==0
+ *   flags      MI_CLAMP_EPS for the DDIM variant */
+int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, int W,
+               const int32_t* t_list, int n_iters,
+               const float* beta, const float* alpha, const float* alpha_hat, int noise_steps,
+               const float* step_noise, int flags,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug/test hook: after a forward call, copies the output of the named top-level module
+ * (e.g. "downs.3", "mid_attn", "ups.6") from the workspace to `dst` (device fp32, NCHW
+ * [B,C,h,w]); returns its C,h,w.  `dst` may be NULL to query the shape only. */
+int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int H, int W,
+                   const void* workspace, float* dst, int* C, int* h, int* w, void* stream);
+
+/* Kernel-level timing of the last mi_denoise/mi_unet_forward... is left to HIP events /
+ * rocprofv3 on the caller's stream. */
+
+void mi_plan_destroy(mi_plan* plan);
+
+/* Thread-local, never NULL. */
+const char* mi_last_error(void);
+
+/* Library version string, e.g. "midd 0.1 gfx950". */
+const char* mi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDD_H */

@@ -8,3 +8,5 @@ the C ABI declared in ``include/midd.h``.  There is no CPU fallback: without the
 ``libmidd.so`` and a GPU every compute call raises.
 """
 from .config import UNetConfig, topology, param_shapes, timestep_list  # noqa: F401
+from .modules import UNetDiffusion  # noqa: F401
+from .sampler import DiffusionDenoiser, device  # noqa: F401

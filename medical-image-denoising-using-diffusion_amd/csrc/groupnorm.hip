@@ -1,0 +1,127 @@
+// GroupNorm(8, C) statistics for NHWC fp32 activations (torch.cat of two sources allowed).
+//
+// Replaces the statistics half of nn.GroupNorm(8, C) on the reference's hot path
+// (/root/reference/Backend/DDIM/DDIMModel.py:116,121,139,214; eps = 1e-5, affine).  The
+// normalise/affine half is never a separate pass: this kernel emits, per (sample, channel),
+//     scale = rstd * gamma            shift = beta - mean * rstd * gamma
+// and the consuming convolution applies x*scale+shift (+SiLU) while staging its input.
+//
+// Two launches, both deterministic (fixed summation order, no atomics):
+//   gn_partial : grid (nsplit, B); each block sums a contiguous pixel range in fp64
+//                (products of fp32 values are exact in fp64, so E[x^2]-mean^2 does not cancel)
+//   gn_finalize: grid (B); folds the nsplit partials in order, writes scale/shift.
+// HBM-bound: one read of the tensor.
+#include "midd_internal.h"
+
+namespace midd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_GROUPS_ = 8;
+
+__global__ __launch_bounds__(GN_THREADS)
+void gn_partial_kernel(const GnArgs a) {
+    extern __shared__ double red[];               // [ppi][C][2]
+    const int C = a.C0 + a.C1;
+    const int CQ = C >> 2;
+    const int ppi = GN_THREADS / CQ;              // pixels per iteration
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, split = blockIdx.x;
+    const int pl = tid / CQ, q = tid - pl * CQ;
+    const int per = (a.HW + a.nsplit - 1) / a.nsplit;
+    const int p0 = split * per;
+    const int p1 = min(a.HW, p0 + per);
+
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    if (pl < ppi) {
+        const int ch = q * 4;
+        const float* src; int Cs, coff;
+        if (ch < a.C0) { src = a.src0; Cs = a.C0; coff = ch; }
+        else           { src = a.src1; Cs = a.C1; coff = ch - a.C0; }
+        const float* base = src + (size_t)b * a.HW * Cs + coff;
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * Cs);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)v[e];
+                s[e] += d;
+                ss[e] = fma(d, d, ss[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[((size_t)pl * C + ch + e) * 2 + 0] = s[e];
+            red[((size_t)pl * C + ch + e) * 2 + 1] = ss[e];
+        }
+    }
+    __syncthreads();
+    // per-channel fold over the pixel lanes (fixed order), then per-group fold over channels
+    for (int c = tid; c < C; c += GN_THREADS) {
+        double cs = 0, css = 0;
+        for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
+        red[(size_t)c * 2] = cs; red[(size_t)c * 2 + 1] = css;      // lane-0 row is only read by its own channel thread
+    }
+    __syncthreads();
+    if (tid < GN_GROUPS_) {
+        const int cg = C / GN_GROUPS_;
+        double gs = 0, gss = 0;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { gs += red[(size_t)c * 2]; gss += red[(size_t)c * 2 + 1]; }
+        double* o = a.partial + (((size_t)b * a.nsplit + split) * GN_GROUPS_ + tid) * 2;
+        o[0] = gs; o[1] = gss;
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS)
+void gn_finalize_kernel(const GnArgs a) {
+    __shared__ float s_mean_rstd[GN_GROUPS_][2];
+    const int C = a.C0 + a.C1;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < GN_GROUPS_) {
+        double gs = 0, gss = 0;
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+            const double* p = a.partial + (((size_t)b * a.nsplit + sp) * GN_GROUPS_ + tid) * 2;
+            gs += p[0]; gss += p[1];
+        }
+        const double n = (double)a.HW * (C / GN_GROUPS_);
+        const double mean = gs / n;
+        double var = gss / n - mean * mean;          // biased variance, as torch's group_norm
+        if (var < 0) var = 0;
+        s_mean_rstd[tid][0] = (float)mean;
+        s_mean_rstd[tid][1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    const int cg = C / GN_GROUPS_;
+    for (int c = tid; c < C; c += GN_THREADS) {
+        const int g = c / cg;
+        const float sc = s_mean_rstd[g][1] * a.gamma[c];
+        a.scale[(size_t)b * C + c] = sc;
+        a.shift[(size_t)b * C + c] = a.beta[c] - s_mean_rstd[g][0] * sc;
+    }
+}
+
+int gn_pick_nsplit(int B, int HW, int C) {
+    // Independent of B on purpose: the partial-sum order (hence the bits of mean/rstd) of an
+    // image must not change with the batch it is processed in (multi-GPU shards == single GPU).
+    (void)B;
+    const int ppi = GN_THREADS / (C / 4);
+    int ns = HW / (ppi * 8);          // >= 8 pixels per lane-row per block
+    if (ns < 1) ns = 1;
+    if (ns > 128) ns = 128;
+    return ns;
+}
+
+hipError_t gn_stats_launch(const GnArgs& a, hipStream_t s) {
+    const int C = a.C0 + a.C1;
+    if (C % 8 || C / 4 > GN_THREADS) return hipErrorInvalidValue;    // 8 groups, float4 loads
+    if (a.C0 % 4 || a.C1 % 4) return hipErrorInvalidValue;
+    const int ppi = GN_THREADS / (C / 4);
+    const size_t lds = (size_t)ppi * C * 2 * sizeof(double);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(a.nsplit, a.B), dim3(GN_THREADS), lds, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.B), dim3(GN_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace midd

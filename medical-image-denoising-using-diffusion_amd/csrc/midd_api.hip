@@ -1,0 +1,750 @@
+// Host side of libmidd.so: C ABI (include/midd.h), topology, weight repacking, timestep
+// table, execution planner and the sampler loop.  No torch, no allocation on the hot path.
+//
+// Reference interfaces replaced (cited per function below):
+//   UNetDiffusion.__init__ / forward   /root/reference/Backend/DDIM/DDIMModel.py:169-248
+//   DiffusionDenoiser.denoise          /root/reference/Backend/DDIM/DDIMModel.py:268-289
+//   cddpm variants                     /root/reference/Backend/cddpm/cddpmModels.py:176-308
+#include "../../include/midd.h"
+#include "midd_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace midd;
+
+static const int ATTN_HEADS_ABI = 2;     // AttentionBlock(num_heads=2), DDIMModel.py:136
+
+// ------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(MI_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------ topology
+enum ModKind { MOD_RB, MOD_ATTN, MOD_DOWN, MOD_UP };
+struct Mod {
+    ModKind kind;
+    std::string name;
+    int in_c, out_c;
+    int temb_col = -1;       // column offset into the time table (residual blocks)
+    // device offsets (floats) into the packed weight buffer, filled by finalize
+    size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, wr = 0, br = 0;       // rb: conv1, conv2, res_conv
+    size_t g1 = 0, be1 = 0, g2 = 0, be2 = 0;                      // rb / attn GroupNorm affine
+    size_t wq = 0, bq = 0, wp = 0, bp = 0;                        // attn: qkv, proj
+    size_t wc = 0, bc = 0, wt = 0;                                // down / up(folded 3x3) conv, raw ConvT
+};
+
+struct HostWeight { std::vector<int64_t> shape; std::vector<float> data; bool loaded = false; };
+
+struct TensorRef { size_t off = 0; int C = 0, H = 0, W = 0; };
+
+enum OpKind { OP_IN_CONV, OP_GN, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT };
+struct Op {
+    OpKind kind;
+    // sources / destination (workspace offsets in bytes)
+    TensorRef s0, s1, dst, resid;
+    bool has_s1 = false, has_resid = false;
+    // OP_GN
+    size_t gamma = 0, beta = 0, scale_off = 0, shift_off = 0, partial_off = 0;
+    int nsplit = 1;
+    // OP_CONV
+    size_t w = 0, b = 0;
+    int prologue = PRO_RAW, temb_col = -1;
+    ConvTile tile{};
+    int stride = 1, ks = 3;
+};
+
+struct Program {
+    int B, H, W;
+    std::vector<Op> ops;
+    size_t bytes = 0, trow_off = 0;
+    std::map<std::string, TensorRef> outputs;
+};
+
+struct mi_plan {
+    mi_unet_cfg cfg{};
+    std::vector<Mod> downs, mid, ups;
+    int final_c = 0, temb_cols = 0, levels = 0;
+    std::vector<std::string> expected;                       // state-dict key order
+    std::map<std::string, std::vector<int64_t>> expected_shape;
+    std::map<std::string, HostWeight> host;
+    // device side
+    float* wdev = nullptr; size_t wdev_floats = 0;
+    float* ttab = nullptr; int time_rows = 0;
+    size_t w_in = 0, b_in = 0, g_out = 0, be_out = 0, w_out = 0, b_out = 0;
+    bool finalized = false;
+    int device = -1;
+    std::mutex mu;
+    std::map<uint64_t, std::unique_ptr<Program>> programs;
+};
+
+static bool is_attn_level(const mi_unet_cfg& c, int i) {
+    for (int k = 0; k < c.num_attention_levels; ++k) if (c.attention_levels[k] == i) return true;
+    return false;
+}
+
+static void expect(mi_plan* p, const std::string& name, std::vector<int64_t> shape) {
+    p->expected.push_back(name);
+    p->expected_shape[name] = std::move(shape);
+}
+static void expect_conv(mi_plan* p, const std::string& n, int cin, int cout, int k) {
+    expect(p, n + ".weight", {cout, cin, k, k}); expect(p, n + ".bias", {cout});
+}
+static void expect_vec2(mi_plan* p, const std::string& n, int c) { expect(p, n + ".weight", {c}); expect(p, n + ".bias", {c}); }
+static void expect_linear(mi_plan* p, const std::string& n, int cin, int cout) {
+    expect(p, n + ".weight", {cout, cin}); expect(p, n + ".bias", {cout});
+}
+
+static void expect_mod(mi_plan* p, const Mod& m) {
+    const int te = p->cfg.time_emb_dim;
+    switch (m.kind) {
+        case MOD_RB:
+            expect_linear(p, m.name + ".time_mlp.1", te, m.out_c);
+            expect_vec2(p, m.name + ".block1.0", m.in_c);
+            expect_conv(p, m.name + ".block1.2", m.in_c, m.out_c, 3);
+            expect_vec2(p, m.name + ".block2.0", m.out_c);
+            expect_conv(p, m.name + ".block2.3", m.out_c, m.out_c, 3);
+            if (m.in_c != m.out_c) expect_conv(p, m.name + ".res_conv", m.in_c, m.out_c, 1);
+            break;
+        case MOD_ATTN:
+            expect_vec2(p, m.name + ".norm", m.in_c);
+            expect_conv(p, m.name + ".qkv", m.in_c, 3 * m.in_c, 1);
+            expect_conv(p, m.name + ".proj", m.in_c, m.in_c, 1);
+            break;
+        case MOD_DOWN: expect_conv(p, m.name, m.in_c, m.out_c, 3); break;
+        case MOD_UP:
+            expect(p, m.name + ".weight", {m.in_c, m.out_c, 4, 4});
+            expect(p, m.name + ".bias", {m.out_c});
+            break;
+    }
+}
+
+// Mirrors the module lists built by UNetDiffusion.__init__ (DDIMModel.py:182-211; cddpm
+// bookkeeping cddpmModels.py:191-221).
+static int build_topology(mi_plan* p) {
+    const mi_unet_cfg& c = p->cfg;
+    const int mc = c.model_channels, nres = c.num_levels;
+    int ch = mc;
+    std::vector<int> down_channels;
+    auto idx_name = [](const char* pre, size_t i) { return std::string(pre) + "." + std::to_string(i); };
+    for (int i = 0; i < nres; ++i) {
+        const int out_ch = mc * c.channel_mult[i];
+        for (int r = 0; r < c.num_res_blocks; ++r) {
+            p->downs.push_back(Mod{MOD_RB, idx_name("downs", p->downs.size()), ch, out_ch});
+            ch = out_ch; down_channels.push_back(ch);
+            if (is_attn_level(c, i)) {
+                p->downs.push_back(Mod{MOD_ATTN, idx_name("downs", p->downs.size()), ch, ch});
+                down_channels.push_back(ch);
+            }
+        }
+        if (i != nres - 1) {
+            p->downs.push_back(Mod{MOD_DOWN, idx_name("downs", p->downs.size()), ch, ch});
+            down_channels.push_back(ch);
+        }
+    }
+    p->mid.push_back(Mod{MOD_RB, "mid_block1", ch, ch});
+    p->mid.push_back(Mod{MOD_ATTN, "mid_attn", ch, ch});
+    p->mid.push_back(Mod{MOD_RB, "mid_block2", ch, ch});
+    for (int i = nres - 1; i >= 0; --i) {
+        const int out_ch = mc * c.channel_mult[i];
+        for (int j = 0; j < c.num_res_blocks + 1; ++j) {
+            int in_ch;
+            if (c.variant == MI_VARIANT_DDIM) in_ch = ch + ch;
+            else {
+                if (down_channels.empty()) return fail(MI_EINVAL, "cddpm topology: skip stack underflow");
+                in_ch = ch + down_channels.back(); down_channels.pop_back();
+            }
+            p->ups.push_back(Mod{MOD_RB, idx_name("ups", p->ups.size()), in_ch, out_ch});
+            ch = out_ch;
+            if (is_attn_level(c, i) && (c.variant == MI_VARIANT_DDIM || j == 0))
+                p->ups.push_back(Mod{MOD_ATTN, idx_name("ups", p->ups.size()), ch, ch});
+        }
+        if (i != 0) p->ups.push_back(Mod{MOD_UP, idx_name("ups", p->ups.size()), ch, ch});
+    }
+    p->final_c = ch;
+    p->levels = nres;
+
+    int col = 0;
+    auto assign_cols = [&](std::vector<Mod>& v) { for (Mod& m : v) if (m.kind == MOD_RB) { m.temb_col = col; col += m.out_c; } };
+    assign_cols(p->downs); assign_cols(p->mid); assign_cols(p->ups);
+    p->temb_cols = col;
+
+    expect_linear(p, "time_mlp.1", mc, c.time_emb_dim);
+    expect_linear(p, "time_mlp.3", c.time_emb_dim, c.time_emb_dim);
+    expect_conv(p, "in_conv", 2 * c.in_channels, mc, 3);
+    for (const Mod& m : p->downs) expect_mod(p, m);
+    for (const Mod& m : p->mid) expect_mod(p, m);
+    for (const Mod& m : p->ups) expect_mod(p, m);
+    expect_vec2(p, "out_conv.0", p->final_c);
+    expect_conv(p, "out_conv.2", p->final_c, c.in_channels, 3);
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------ C ABI: create / load
+extern "C" const char* mi_last_error(void) { return g_err; }
+extern "C" const char* mi_version(void) { return "midd 0.1 gfx950 fp32-mfma"; }
+
+extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
+    if (!cfg || !out) return fail(MI_EINVAL, "null argument");
+    if (cfg->num_levels < 1 || cfg->num_levels > MI_MAX_LEVELS) return fail(MI_EINVAL, "num_levels out of range");
+    if (cfg->num_attention_levels < 0 || cfg->num_attention_levels > MI_MAX_LEVELS) return fail(MI_EINVAL, "num_attention_levels out of range");
+    if (cfg->model_channels < 16 || cfg->model_channels % 16) return fail(MI_EINVAL, "model_channels must be a multiple of 16 (MFMA K-chunk), got %d", cfg->model_channels);
+    if (cfg->in_channels < 1 || cfg->in_channels > 4) return fail(MI_EINVAL, "in_channels must be 1..4");
+    if (cfg->num_res_blocks < 1) return fail(MI_EINVAL, "num_res_blocks must be >= 1");
+    if (cfg->time_emb_dim < 1) return fail(MI_EINVAL, "time_emb_dim must be >= 1");
+    if (cfg->variant != MI_VARIANT_DDIM && cfg->variant != MI_VARIANT_CDDPM) return fail(MI_EINVAL, "unknown variant %d", cfg->variant);
+    for (int i = 0; i < cfg->num_levels; ++i)
+        if (cfg->channel_mult[i] < 1) return fail(MI_EINVAL, "channel_mult[%d] must be >= 1", i);
+    for (int i = 0; i < cfg->num_attention_levels; ++i) {
+        const int lv = cfg->attention_levels[i];
+        if (lv >= 0 && lv < cfg->num_levels) {
+            const int c = cfg->model_channels * cfg->channel_mult[lv];
+            if (c % ATTN_HEADS_ABI || !attention_supported(c / 2))
+                return fail(MI_EINVAL, "attention head_dim %d unsupported (32/64/96/128)", c / 2);
+        }
+    }
+    std::unique_ptr<mi_plan> p(new mi_plan());
+    p->cfg = *cfg;
+    int rc = build_topology(p.get());
+    if (rc) return rc;
+    *out = p.release();
+    return MI_OK;
+}
+
+extern "C" int mi_unet_num_weights(const mi_plan* plan) { return plan ? (int)plan->expected.size() : 0; }
+extern "C" const char* mi_unet_weight_name(const mi_plan* plan, int i) {
+    if (!plan || i < 0 || i >= (int)plan->expected.size()) return nullptr;
+    return plan->expected[i].c_str();
+}
+
+extern "C" int mi_unet_load_weights(mi_plan* plan, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!plan || !key || !data || !shape) return fail(MI_EINVAL, "null argument");
+    auto it = plan->expected_shape.find(key);
+    if (it == plan->expected_shape.end()) return fail(MI_EINVAL, "unexpected key in state_dict: \"%s\"", key);
+    const std::vector<int64_t>& want = it->second;
+    bool ok = (int)want.size() == ndim;
+    for (int i = 0; ok && i < ndim; ++i) ok = want[i] == shape[i];
+    if (!ok) return fail(MI_EINVAL, "size mismatch for %s", key);
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    std::lock_guard<std::mutex> lk(plan->mu);
+    HostWeight& hw = plan->host[key];
+    hw.shape.assign(shape, shape + ndim);
+    hw.data.assign(data, data + n);
+    hw.loaded = true;
+    plan->finalized = false;
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------ weight packing
+struct Packer {
+    std::vector<float> buf;
+    size_t put(const float* p, size_t n) {               // 64-float (256 B) aligned
+        size_t off = (buf.size() + 63) & ~(size_t)63;
+        buf.resize(off + n);
+        memcpy(buf.data() + off, p, n * sizeof(float));
+        return off;
+    }
+    size_t put(const std::vector<float>& v) { return put(v.data(), v.size()); }
+};
+
+// torch Conv2d weight [Cout][Cin][KS][KS]  ->  [Cin/16][KS*KS][Cout/16][lane 64][4]
+// lane = kq*16 + n holds W[cout = 16*tile + n][cin = 16*chunk + 4*kq + j][tap] in element j:
+// the A-operand fragment order of conv_mfma_f32.hip.
+static std::vector<float> pack_conv(const float* w, int Cout, int Cin, int KS) {
+    const int taps = KS * KS, nch = Cin / 16, ntile = Cout / 16;
+    std::vector<float> out((size_t)nch * taps * ntile * 256);
+    for (int c = 0; c < nch; ++c)
+        for (int t = 0; t < taps; ++t)
+            for (int nt = 0; nt < ntile; ++nt)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int n = lane & 15, kq = lane >> 4;
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = nt * 16 + n, ci = c * 16 + kq * 4 + j;
+                        out[((((size_t)c * taps + t) * ntile + nt) * 64 + lane) * 4 + j] =
+                            w[((size_t)co * Cin + ci) * taps + t];
+                    }
+                }
+    return out;
+}
+
+// ConvTranspose2d(4,2,1) followed by the bilinear half-size resample (an exact 2x2 mean for
+// align_corners=False) == one 3x3/s1/p1 conv with
+//   W_eff[co][ci][d][e] = 1/4 * sum_{a,b in {0,1}} W[ci][co][a-2d+3][b-2e+3]   (indices within 0..3)
+// (DDIMModel.py:211 + :241-242; identity checked in tests/test_oracle_vs_reference.py).
+static std::vector<float> fold_convt(const float* w /*[Cin][Cout][4][4]*/, int Cin, int Cout) {
+    std::vector<float> eff((size_t)Cout * Cin * 9, 0.f);
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co)
+            for (int d = 0; d < 3; ++d)
+                for (int e = 0; e < 3; ++e) {
+                    float acc = 0.f;
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            const int ky = a - 2 * d + 3, kx = b - 2 * e + 3;
+                            if (ky >= 0 && ky < 4 && kx >= 0 && kx < 4)
+                                acc += w[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+                        }
+                    eff[(((size_t)co * Cin + ci) * 3 + d) * 3 + e] = 0.25f * acc;
+                }
+    return eff;
+}
+
+static const HostWeight* getw(mi_plan* p, const std::string& k) {
+    auto it = p->host.find(k);
+    return (it != p->host.end() && it->second.loaded) ? &it->second : nullptr;
+}
+
+static inline float silu_h(float v) { return v / (1.0f + expf(-v)); }
+
+static void linear_h(const float* w, const float* b, const float* x, float* y, int cin, int cout) {
+    for (int o = 0; o < cout; ++o) {
+        float acc = 0.f;
+        const float* wr = w + (size_t)o * cin;
+        for (int i = 0; i < cin; ++i) acc += wr[i] * x[i];
+        y[o] = acc + b[o];
+    }
+}
+
+// time_mlp of the network (DDIMModel.py:99-106,173-178) followed by each ResidualBlock's
+// Linear(SiLU(t_emb)) (DDIMModel.py:111-114,130), for t = 0..rows-1 -> [rows][temb_cols] fp32.
+static std::vector<float> build_time_table(mi_plan* p, int rows) {
+    const int mc = p->cfg.model_channels, te = p->cfg.time_emb_dim, half = mc / 2;
+    const HostWeight *w1 = getw(p, "time_mlp.1.weight"), *b1 = getw(p, "time_mlp.1.bias");
+    const HostWeight *w3 = getw(p, "time_mlp.3.weight"), *b3 = getw(p, "time_mlp.3.bias");
+    std::vector<float> freqs(half);
+    // math.log(10000)/(half-1) is a Python double; arange(half) * -k promotes the scalar to fp32
+    const float k = (float)(-(std::log(10000.0) / (double)(half - 1)));
+    for (int j = 0; j < half; ++j) freqs[j] = expf((float)j * k);
+    std::vector<float> table((size_t)rows * p->temb_cols);
+    std::vector<float> e(mc), h1(te), temb(te), act(te);
+    std::vector<const Mod*> rbs;
+    for (auto* v : {&p->downs, &p->mid, &p->ups}) for (const Mod& m : *v) if (m.kind == MOD_RB) rbs.push_back(&m);
+    for (int t = 0; t < rows; ++t) {
+        for (int j = 0; j < half; ++j) {
+            const float arg = (float)t * freqs[j];
+            e[j] = sinf(arg); e[half + j] = cosf(arg);
+        }
+        linear_h(w1->data.data(), b1->data.data(), e.data(), h1.data(), mc, te);
+        for (int i = 0; i < te; ++i) h1[i] = silu_h(h1[i]);
+        linear_h(w3->data.data(), b3->data.data(), h1.data(), temb.data(), te, te);
+        for (int i = 0; i < te; ++i) act[i] = silu_h(temb[i]);
+        for (const Mod* m : rbs) {
+            const HostWeight *w = getw(p, m->name + ".time_mlp.1.weight"), *b = getw(p, m->name + ".time_mlp.1.bias");
+            linear_h(w->data.data(), b->data.data(), act.data(), &table[(size_t)t * p->temb_cols + m->temb_col], te, m->out_c);
+        }
+    }
+    return table;
+}
+
+extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
+    if (!plan) return fail(MI_EINVAL, "null plan");
+    if (time_rows < 1) return fail(MI_EINVAL, "time_rows must be >= 1");
+    std::lock_guard<std::mutex> lk(plan->mu);
+    for (const std::string& k : plan->expected)
+        if (!getw(plan, k)) return fail(MI_ESTATE, "missing key in state_dict: \"%s\"", k.c_str());
+
+    Packer pk;
+    auto W = [&](const std::string& k) { return getw(plan, k)->data.data(); };
+    auto put_raw = [&](const std::string& k) { return pk.put(getw(plan, k)->data); };
+    auto pack_mod = [&](Mod& m) {
+        switch (m.kind) {
+            case MOD_RB:
+                m.g1 = put_raw(m.name + ".block1.0.weight"); m.be1 = put_raw(m.name + ".block1.0.bias");
+                m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3)); m.b1 = put_raw(m.name + ".block1.2.bias");
+                m.g2 = put_raw(m.name + ".block2.0.weight"); m.be2 = put_raw(m.name + ".block2.0.bias");
+                m.w2 = pk.put(pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3)); m.b2 = put_raw(m.name + ".block2.3.bias");
+                if (m.in_c != m.out_c) {
+                    m.wr = pk.put(pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1)); m.br = put_raw(m.name + ".res_conv.bias");
+                }
+                break;
+            case MOD_ATTN:
+                m.g1 = put_raw(m.name + ".norm.weight"); m.be1 = put_raw(m.name + ".norm.bias");
+                m.wq = pk.put(pack_conv(W(m.name + ".qkv.weight"), 3 * m.in_c, m.in_c, 1)); m.bq = put_raw(m.name + ".qkv.bias");
+                m.wp = pk.put(pack_conv(W(m.name + ".proj.weight"), m.in_c, m.in_c, 1)); m.bp = put_raw(m.name + ".proj.bias");
+                break;
+            case MOD_DOWN:
+                m.wc = pk.put(pack_conv(W(m.name + ".weight"), m.out_c, m.in_c, 3)); m.bc = put_raw(m.name + ".bias");
+                break;
+            case MOD_UP: {
+                const float* w = W(m.name + ".weight");
+                std::vector<float> eff = fold_convt(w, m.in_c, m.out_c);
+                m.wc = pk.put(pack_conv(eff.data(), m.out_c, m.in_c, 3)); m.bc = put_raw(m.name + ".bias");
+                // raw layout [ky][kx][Cin][Cout] for the direct fallback kernel
+                std::vector<float> raw((size_t)16 * m.in_c * m.out_c);
+                for (int ci = 0; ci < m.in_c; ++ci) for (int co = 0; co < m.out_c; ++co)
+                    for (int ky = 0; ky < 4; ++ky) for (int kx = 0; kx < 4; ++kx)
+                        raw[(((size_t)(ky * 4 + kx)) * m.in_c + ci) * m.out_c + co] = w[(((size_t)ci * m.out_c + co) * 4 + ky) * 4 + kx];
+                m.wt = pk.put(raw);
+                break;
+            }
+        }
+    };
+    for (Mod& m : plan->downs) pack_mod(m);
+    for (Mod& m : plan->mid) pack_mod(m);
+    for (Mod& m : plan->ups) pack_mod(m);
+    {   // in_conv [Cout][2ic][3][3] -> [tap][2ic][Cout]
+        const int ci2 = 2 * plan->cfg.in_channels, co = plan->cfg.model_channels;
+        const float* w = W("in_conv.weight");
+        std::vector<float> t((size_t)9 * ci2 * co);
+        for (int o = 0; o < co; ++o) for (int i = 0; i < ci2; ++i) for (int tap = 0; tap < 9; ++tap)
+            t[((size_t)tap * ci2 + i) * co + o] = w[((size_t)o * ci2 + i) * 9 + tap];
+        plan->w_in = pk.put(t); plan->b_in = put_raw("in_conv.bias");
+    }
+    {   // out_conv.2 [ic][C][3][3] -> [ic][tap][C]
+        const int ic = plan->cfg.in_channels, C = plan->final_c;
+        const float* w = W("out_conv.2.weight");
+        std::vector<float> t((size_t)ic * 9 * C);
+        for (int o = 0; o < ic; ++o) for (int c = 0; c < C; ++c) for (int tap = 0; tap < 9; ++tap)
+            t[((size_t)o * 9 + tap) * C + c] = w[((size_t)o * C + c) * 9 + tap];
+        plan->g_out = put_raw("out_conv.0.weight"); plan->be_out = put_raw("out_conv.0.bias");
+        plan->w_out = pk.put(t); plan->b_out = put_raw("out_conv.2.bias");
+    }
+    std::vector<float> table = build_time_table(plan, time_rows);
+
+    HIPCHK(hipGetDevice(&plan->device));
+    if (plan->wdev) { HIPCHK(hipFree(plan->wdev)); plan->wdev = nullptr; }
+    if (plan->ttab) { HIPCHK(hipFree(plan->ttab)); plan->ttab = nullptr; }
+    HIPCHK(hipMalloc((void**)&plan->wdev, pk.buf.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(plan->wdev, pk.buf.data(), pk.buf.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&plan->ttab, table.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(plan->ttab, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+    plan->wdev_floats = pk.buf.size();
+    plan->time_rows = time_rows;
+    plan->finalized = true;
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------ planner
+struct Bump {
+    size_t cur = 0;
+    size_t take(size_t bytes) { size_t o = (cur + 255) & ~(size_t)255; cur = o + bytes; return o; }
+};
+
+struct Builder {
+    mi_plan* p; Program* g; Bump bump; int B;
+    TensorRef alloc(int C, int H, int W) {
+        TensorRef t; t.C = C; t.H = H; t.W = W;
+        t.off = bump.take((size_t)B * H * W * C * sizeof(float));
+        return t;
+    }
+    // GroupNorm statistics op; returns its index so consumers can find scale/shift
+    int gn(const TensorRef& s0, const TensorRef* s1, size_t gamma, size_t beta) {
+        Op o{}; o.kind = OP_GN; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
+        const int C = s0.C + (s1 ? s1->C : 0);
+        o.gamma = gamma; o.beta = beta;
+        o.nsplit = gn_pick_nsplit(B, s0.H * s0.W, C);
+        o.scale_off = bump.take((size_t)B * C * sizeof(float));
+        o.shift_off = bump.take((size_t)B * C * sizeof(float));
+        o.partial_off = bump.take((size_t)B * o.nsplit * 16 * sizeof(double));
+        g->ops.push_back(o);
+        return (int)g->ops.size() - 1;
+    }
+    int conv(const TensorRef& s0, const TensorRef* s1, const TensorRef& dst, size_t w, size_t b, int ks, int stride,
+             int prologue, int gn_op, int temb_col, const TensorRef* resid) {
+        Op o{}; o.kind = OP_CONV; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
+        o.dst = dst; o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
+        if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
+        if (resid) { o.resid = *resid; o.has_resid = true; }
+        if (!conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile))
+            return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
+        g->ops.push_back(o);
+        return MI_OK;
+    }
+};
+
+static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
+    const mi_unet_cfg& c = p->cfg;
+    const int div = 1 << (p->levels - 1);
+    if (B < 1 || H < div || W < div || H % div || W % div)
+        return fail(MI_EINVAL, "H and W must be positive multiples of %d (got %dx%d), B >= 1", div, H, W);
+    g->B = B; g->H = H; g->W = W;
+    Builder bld{p, g, Bump{}, B};
+    g->trow_off = bld.bump.take((size_t)B * sizeof(int));
+    int rc;
+
+    auto run_rb = [&](const Mod& m, const TensorRef& s0, const TensorRef* s1, TensorRef* out) -> int {
+        const int cin = s0.C + (s1 ? s1->C : 0);
+        if (cin != m.in_c) return fail(MI_EINVAL, "%s: expected %d input channels, graph provides %d", m.name.c_str(), m.in_c, cin);
+        const int g1 = bld.gn(s0, s1, m.g1, m.be1);
+        TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
+        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, 3, 1, PRO_GN_SILU, g1, m.temb_col, nullptr))) return rc;
+        const int g2 = bld.gn(h1, nullptr, m.g2, m.be2);
+        TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
+        if (m.in_c != m.out_c) {
+            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, 1, 1, PRO_RAW, -1, -1, nullptr))) return rc;   // res_conv(x)
+            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, 3, 1, PRO_GN_SILU, g2, -1, &o))) return rc;   // + in place
+        } else {
+            if (s1) return fail(MI_EINVAL, "%s: identity residual over a concatenated input", m.name.c_str());
+            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, 3, 1, PRO_GN_SILU, g2, -1, &s0))) return rc;
+        }
+        *out = o;
+        return MI_OK;
+    };
+    auto run_attn = [&](const Mod& m, const TensorRef& x, TensorRef* out) -> int {
+        const int C = x.C;
+        const int gi = bld.gn(x, nullptr, m.g1, m.be1);
+        TensorRef qkv = bld.alloc(3 * C, x.H, x.W);
+        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, 1, 1, PRO_GN, gi, -1, nullptr))) return rc;
+        TensorRef att = bld.alloc(C, x.H, x.W);
+        Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = att; g->ops.push_back(o);
+        TensorRef y = bld.alloc(C, x.H, x.W);
+        if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, 1, 1, PRO_RAW, -1, -1, &x))) return rc;
+        *out = y;
+        return MI_OK;
+    };
+
+    TensorRef h = bld.alloc(c.model_channels, H, W);
+    { Op o{}; o.kind = OP_IN_CONV; o.dst = h; g->ops.push_back(o); }
+    g->outputs["in_conv"] = h;
+    std::vector<TensorRef> skips;
+    for (const Mod& m : p->downs) {
+        TensorRef o;
+        if (m.kind == MOD_RB) { if ((rc = run_rb(m, h, nullptr, &o))) return rc; }
+        else if (m.kind == MOD_ATTN) { if ((rc = run_attn(m, h, &o))) return rc; }
+        else {
+            o = bld.alloc(m.out_c, h.H / 2, h.W / 2);     // 3x3 stride 2 pad 1 on even sizes
+            if ((rc = bld.conv(h, nullptr, o, m.wc, m.bc, 3, 2, PRO_RAW, -1, -1, nullptr))) return rc;
+        }
+        h = o; skips.push_back(h); g->outputs[m.name] = h;       // every down module pushes a skip (DDIMModel.py:232)
+    }
+    for (const Mod& m : p->mid) {
+        TensorRef o;
+        if (m.kind == MOD_RB) { if ((rc = run_rb(m, h, nullptr, &o))) return rc; }
+        else { if ((rc = run_attn(m, h, &o))) return rc; }
+        h = o; g->outputs[m.name] = h;
+    }
+    const Mod* pending_up = nullptr;         // a ConvTranspose whose execution is deferred to its consumer
+    auto flush_up = [&]() -> int {           // materialise the pending ConvTranspose for real
+        if (!pending_up) return MI_OK;
+        TensorRef o = bld.alloc(pending_up->out_c, h.H * 2, h.W * 2);
+        Op op{}; op.kind = OP_CONVT; op.s0 = h; op.dst = o; op.w = pending_up->wt; op.b = pending_up->bc;
+        g->ops.push_back(op);
+        g->outputs[pending_up->name] = o;
+        h = o; pending_up = nullptr;
+        return MI_OK;
+    };
+    for (const Mod& m : p->ups) {
+        if (m.kind == MOD_UP) { if ((rc = flush_up())) return rc; pending_up = &m; continue; }
+        if (m.kind == MOD_ATTN) {
+            if ((rc = flush_up())) return rc;
+            TensorRef o; if ((rc = run_attn(m, h, &o))) return rc;
+            h = o; g->outputs[m.name] = h; continue;
+        }
+        if (skips.empty()) return fail(MI_EINVAL, "%s: skip stack empty", m.name.c_str());
+        TensorRef skip = skips.back(); skips.pop_back();          // only residual blocks pop (DDIMModel.py:240)
+        if (pending_up) {
+            if (skip.H == h.H && skip.W == h.W) {
+                // ConvTranspose(4,2,1) then bilinear back to the skip's (half) size: one folded 3x3
+                TensorRef o = bld.alloc(pending_up->out_c, h.H, h.W);
+                if ((rc = bld.conv(h, nullptr, o, pending_up->wc, pending_up->bc, 3, 1, PRO_RAW, -1, -1, nullptr))) return rc;
+                h = o; pending_up = nullptr;
+            } else if ((rc = flush_up())) return rc;
+        }
+        if (h.H != skip.H || h.W != skip.W) {                      // F.interpolate(..., bilinear) (DDIMModel.py:241-242)
+            TensorRef o = bld.alloc(h.C, skip.H, skip.W);
+            Op op{}; op.kind = OP_RESIZE; op.s0 = h; op.dst = o; g->ops.push_back(op);
+            h = o;
+        }
+        TensorRef o; if ((rc = run_rb(m, h, &skip, &o))) return rc;
+        h = o; g->outputs[m.name] = h;
+    }
+    if ((rc = flush_up())) return rc;
+    if (h.H != H || h.W != W) return fail(MI_EINVAL, "network output is %dx%d for a %dx%d input", h.H, h.W, H, W);
+    const int go = bld.gn(h, nullptr, p->g_out, p->be_out);
+    { Op o{}; o.kind = OP_OUT; o.s0 = h; o.scale_off = g->ops[go].scale_off; o.shift_off = g->ops[go].shift_off; g->ops.push_back(o); }
+    g->bytes = (bld.bump.cur + 255) & ~(size_t)255;
+    return MI_OK;
+}
+
+static int get_program(mi_plan* p, int B, int H, int W, Program** out) {
+    if (!p->finalized) return fail(MI_ESTATE, "mi_unet_finalize has not been called (or weights changed since)");
+    const uint64_t key = ((uint64_t)B << 40) ^ ((uint64_t)H << 20) ^ (uint64_t)W;
+    std::lock_guard<std::mutex> lk(p->mu);
+    auto it = p->programs.find(key);
+    if (it == p->programs.end()) {
+        std::unique_ptr<Program> g(new Program());
+        int rc = build_program(p, B, H, W, g.get());
+        if (rc) return rc;
+        it = p->programs.emplace(key, std::move(g)).first;
+    }
+    *out = it->second.get();
+    return MI_OK;
+}
+
+extern "C" size_t mi_workspace_bytes(mi_plan* plan, int B, int H, int W) {
+    Program* g = nullptr;
+    if (!plan || get_program(plan, B, H, W, &g)) return 0;
+    return g->bytes;
+}
+
+// ------------------------------------------------------------------------------ execution
+struct StepIO {
+    const float* x; const float* cond; float* eps_out;
+    float* x_update; const float* noise; float c1, c2, c3; int clamp_eps;
+};
+
+static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s) {
+    const float* wd = p->wdev;
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const int B = g->B;
+    for (const Op& o : g->ops) {
+        hipError_t e = hipSuccess;
+        switch (o.kind) {
+            case OP_IN_CONV:
+                e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), B, p->cfg.in_channels,
+                                   g->H, g->W, o.dst.C, s);
+                break;
+            case OP_GN: {
+                GnArgs a{};
+                a.src0 = F(o.s0.off); a.C0 = o.s0.C;
+                a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
+                a.B = B; a.HW = o.s0.H * o.s0.W; a.gamma = wd + o.gamma; a.beta = wd + o.beta; a.eps = 1e-5f;
+                a.partial = reinterpret_cast<double*>(ws + o.partial_off); a.nsplit = o.nsplit;
+                a.scale = F(o.scale_off); a.shift = F(o.shift_off);
+                e = gn_stats_launch(a, s);
+                break;
+            }
+            case OP_CONV: {
+                ConvArgs a{};
+                a.src0 = F(o.s0.off); a.C0 = o.s0.C;
+                a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
+                a.B = B; a.H = o.s0.H; a.W = o.s0.W; a.OH = o.dst.H; a.OW = o.dst.W;
+                a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
+                a.prologue = o.prologue;
+                if (o.prologue != PRO_RAW) { a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off); }
+                if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
+                a.resid = o.has_resid ? F(o.resid.off) : nullptr;
+                a.out = F(o.dst.off);
+                e = conv_launch(a, o.tile, s);
+                break;
+            }
+            case OP_ATTN:
+                e = attention_launch(F(o.s0.off), F(o.dst.off), B, o.dst.H * o.dst.W, o.dst.C, 2, s);
+                break;
+            case OP_RESIZE:
+                e = resize_bilinear_launch(F(o.s0.off), F(o.dst.off), B, o.s0.H, o.s0.W, o.s0.C, o.dst.H, o.dst.W, s);
+                break;
+            case OP_CONVT:
+                e = conv_transpose_launch(F(o.s0.off), wd + o.w, wd + o.b, F(o.dst.off), B, o.s0.H, o.s0.W, o.s0.C, o.dst.C, s);
+                break;
+            case OP_OUT: {
+                OutConvArgs a{};
+                a.src = F(o.s0.off); a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off);
+                a.w = wd + p->w_out; a.bias = wd + p->b_out;
+                a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
+                a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;
+                a.c1 = io.c1; a.c2 = io.c2; a.c3 = io.c3; a.clamp_eps = io.clamp_eps;
+                e = out_conv_launch(a, s);
+                break;
+            }
+        }
+        if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
+    }
+    return MI_OK;
+}
+
+static int check_call(mi_plan* plan, int B, int H, int W, void* ws, size_t ws_bytes, Program** g) {
+    if (!plan) return fail(MI_EINVAL, "null plan");
+    int rc = get_program(plan, B, H, W, g);
+    if (rc) return rc;
+    if (!ws || ws_bytes < (*g)->bytes) return fail(MI_ENOMEM, "workspace too small: need %zu bytes, got %zu", (*g)->bytes, ws_bytes);
+    if (((uintptr_t)ws) & 255) return fail(MI_EINVAL, "workspace must be 256-byte aligned");
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != plan->device)
+        return fail(MI_ESTATE, "plan was finalized on device %d but current device is %d", plan->device, dev);
+    return MI_OK;
+}
+
+extern "C" int mi_unet_forward(mi_plan* plan, const float* x, const float* condition, const int32_t* t, float* eps,
+                               int B, int H, int W, void* workspace, size_t workspace_bytes, void* stream) {
+    Program* g = nullptr;
+    int rc = check_call(plan, B, H, W, workspace, workspace_bytes, &g);
+    if (rc) return rc;
+    if (!x || !condition || !t || !eps) return fail(MI_EINVAL, "null argument");
+    for (int i = 0; i < B; ++i)
+        if (t[i] < 0 || t[i] >= plan->time_rows) return fail(MI_EINVAL, "timestep %d outside the precomputed table [0,%d)", t[i], plan->time_rows);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    hipError_t e = fill_i32_launch(reinterpret_cast<int*>(ws + g->trow_off), t, B, s);
+    if (e != hipSuccess) return fail(MI_EHIP, "fill timesteps: %s", hipGetErrorString(e));
+    StepIO io{x, condition, eps, nullptr, nullptr, 0.f, 0.f, 0.f, 0};
+    return run_program(plan, g, io, ws, s);
+}
+
+extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, int W,
+                          const int32_t* t_list, int n_iters,
+                          const float* beta, const float* alpha, const float* alpha_hat, int noise_steps,
+                          const float* step_noise, int flags,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    Program* g = nullptr;
+    int rc = check_call(plan, B, H, W, workspace, workspace_bytes, &g);
+    if (rc) return rc;
+    if (!noisy || !x_out || (n_iters > 0 && !t_list) || !beta || !alpha || !alpha_hat) return fail(MI_EINVAL, "null argument");
+    if (noisy == x_out) return fail(MI_EINVAL, "x_out must not alias noisy (the condition image is read every step)");
+    if (n_iters < 0 || noise_steps < 1 || noise_steps > plan->time_rows)
+        return fail(MI_EINVAL, "noise_steps %d exceeds the precomputed time table (%d rows)", noise_steps, plan->time_rows);
+    for (int i = 0; i < n_iters; ++i)
+        if (t_list[i] < 0 || t_list[i] >= noise_steps) return fail(MI_EINVAL, "t_list[%d]=%d outside [0,%d)", i, t_list[i], noise_steps);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const size_t img_elems = (size_t)B * plan->cfg.in_channels * H * W;
+    HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, s));   // x = noisy_img.clone()
+    for (int i = 0; i < n_iters; ++i) {
+        const int t = t_list[i];
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ws + g->trow_off), t, B, s));                     // t = full((B,), i)
+        StepIO io{};
+        io.x = x_out; io.cond = noisy; io.eps_out = nullptr; io.x_update = x_out;
+        // fp32 arithmetic in the reference's order (DDIMModel.py:280-283)
+        io.c1 = 1.0f / sqrtf(alpha[t]);
+        io.c2 = (1.0f - alpha[t]) / sqrtf(1.0f - alpha_hat[t]);
+        io.c3 = sqrtf(beta[t]);
+        io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems : nullptr;          // cddpmModels.py:297-300
+        io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
+        if ((rc = run_program(plan, g, io, ws, s))) return rc;
+    }
+    return MI_OK;
+}
+
+extern "C" int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int H, int W, const void* workspace,
+                              float* dst, int* C, int* h, int* w, void* stream) {
+    if (!plan || !module_name) return fail(MI_EINVAL, "null argument");
+    Program* g = nullptr;
+    int rc = get_program(plan, B, H, W, &g);
+    if (rc) return rc;
+    auto it = g->outputs.find(module_name);
+    if (it == g->outputs.end()) return fail(MI_EINVAL, "module \"%s\" has no materialised output in this plan", module_name);
+    const TensorRef& t = it->second;
+    if (C) *C = t.C; if (h) *h = t.H; if (w) *w = t.W;
+    if (dst) {
+        if (!workspace) return fail(MI_EINVAL, "null workspace");
+        hipError_t e = nhwc_to_nchw_launch(reinterpret_cast<const float*>((const char*)workspace + t.off), dst, B, t.H, t.W, t.C, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(MI_EHIP, "nhwc_to_nchw: %s", hipGetErrorString(e));
+    }
+    return MI_OK;
+}
+
+extern "C" void mi_plan_destroy(mi_plan* plan) {
+    if (!plan) return;
+    if (plan->wdev) (void)hipFree(plan->wdev);
+    if (plan->ttab) (void)hipFree(plan->ttab);
+    delete plan;
+}

@@ -1,0 +1,88 @@
+// Internal declarations shared by the HIP kernels and the C-ABI host side of libmidd.so.
+// Activations inside the library are fp32 NHWC ([B][H][W][C]); only the boundary tensors
+// ([B,in_channels,H,W], in_channels == 1 in every reference call site) are NCHW.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace midd {
+
+// ---------------------------------------------------------------- implicit-GEMM convolution
+enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
+
+struct ConvArgs {
+    const float* src0;      // NHWC, C0 channels
+    const float* src1;      // NHWC, C1 channels (virtual torch.cat on dim=1); may be null when C1 == 0
+    int C0, C1;
+    int B, H, W;            // input spatial size
+    int OH, OW;             // output spatial size
+    const float* wpack;     // [Cin/16][taps][Cout/16][64 lanes][4]  (MFMA A-fragment order)
+    const float* bias;      // [Cout]
+    int Cout;
+    const float* gn_scale;  // [B][Cin]  rstd*gamma            (prologue != RAW)
+    const float* gn_shift;  // [B][Cin]  beta - mean*rstd*gamma
+    int prologue;
+    const float* temb;      // time table [rows][temb_stride], already offset to this block's column
+    int temb_stride;
+    const int* trow;        // [B] table row per sample
+    const float* resid;     // NHWC [B][OH][OW][Cout] added in the epilogue, or null
+    float* out;             // NHWC [B][OH][OW][Cout]
+    int tiles_x, tiles_y;
+};
+
+struct ConvTile {           // which template instance to launch
+    int ks, stride, tw, mt, nt, wm, wn;
+};
+
+// Picks a tile for (Cout, output pixels, kernel size, stride); returns false if unsupported.
+bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
+hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
+
+// ---------------------------------------------------------------- GroupNorm statistics
+struct GnArgs {
+    const float* src0; const float* src1; int C0, C1;
+    int B, HW;
+    const float* gamma; const float* beta;   // [C]
+    float eps;
+    double* partial;        // [B][nsplit][8][2] scratch
+    int nsplit;
+    float* scale; float* shift;              // [B][C] outputs
+};
+hipError_t gn_stats_launch(const GnArgs& a, hipStream_t s);
+int gn_pick_nsplit(int B, int HW, int C);
+
+// ---------------------------------------------------------------- attention
+// qkv: NHWC [B][N][3C], channel = s*C + head*D + d (s in q,k,v);  out: [B][N][C]
+hipError_t attention_launch(const float* qkv, float* out, int B, int N, int C, int heads, hipStream_t s);
+bool attention_supported(int head_dim);
+
+// ---------------------------------------------------------------- small direct kernels
+// in_conv: Conv3x3 on cat[x, cond] (NCHW [B,ic,H,W] each) -> NHWC [B][H][W][Cout]
+hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9][2ic][Cout]*/, const float* bias,
+                          float* out, int B, int ic, int H, int W, int Cout, hipStream_t s);
+
+struct OutConvArgs {
+    const float* src;       // NHWC [B][H][W][C]
+    const float* gn_scale; const float* gn_shift;   // [B][C]
+    const float* w;         // [ic][9][C]
+    const float* bias;      // [ic]
+    int B, H, W, C, ic;
+    float* eps_out;         // NCHW [B,ic,H,W] raw network output, or null
+    // fused sampler update (DDIMModel.py:278-284) when x != null:  x <- clamp(c1*(x - c2*clamp(eps)) + c3*noise, 0, 1)
+    float* x;               // NCHW [B,ic,H,W], updated in place
+    const float* noise;     // NCHW or null
+    float c1, c2, c3;
+    int clamp_eps;
+};
+hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s);
+
+// bilinear resize NHWC (align_corners=False), any size ratio
+hipError_t resize_bilinear_launch(const float* src, float* dst, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
+// ConvTranspose2d(C,C,4,stride=2,padding=1) direct (only used by topologies where it cannot be folded)
+hipError_t conv_transpose_launch(const float* src, const float* w /*[4][4][Cin][Cout]*/, const float* bias, float* dst,
+                                 int B, int H, int W, int Cin, int Cout, hipStream_t s);
+// NHWC -> NCHW copy (debug fetch)
+hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, hipStream_t s);
+hipError_t fill_i32_launch(int* dst, const int* host_vals, int n, hipStream_t s);
+
+}  // namespace midd

@@ -1,0 +1,87 @@
+"""ctypes binding of libmidd.so (C ABI: include/midd.h).
+
+There is deliberately no fallback: if the shared library is missing or cannot be loaded,
+``lib()`` raises and every compute entry point of the package fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmidd.so")
+
+MI_MAX_LEVELS = 8
+MI_VARIANT = {"ddim": 0, "cddpm": 1}
+MI_CLAMP_EPS = 1
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class MiddError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmidd error {code}: {message}")
+        self.code = code
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("model_channels", C.c_int32), ("num_levels", C.c_int32),
+                ("channel_mult", C.c_int32 * MI_MAX_LEVELS), ("num_res_blocks", C.c_int32),
+                ("num_attention_levels", C.c_int32), ("attention_levels", C.c_int32 * MI_MAX_LEVELS),
+                ("time_emb_dim", C.c_int32), ("variant", C.c_int32)]
+
+
+# every symbol include/midd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("mi_unet_plan_create", C.c_int, [C.POINTER(UNetCfg), C.POINTER(C.c_void_p)]),
+    ("mi_unet_load_weights", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    ("mi_unet_num_weights", C.c_int, [C.c_void_p]),
+    ("mi_unet_weight_name", C.c_char_p, [C.c_void_p, C.c_int]),
+    ("mi_unet_finalize", C.c_int, [C.c_void_p, C.c_int]),
+    ("mi_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    ("mi_unet_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("mi_denoise", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                             C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                             C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("mi_debug_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    ("mi_plan_destroy", None, [C.c_void_p]),
+    ("mi_last_error", C.c_char_p, []),
+    ("mi_version", C.c_char_p, []),
+]
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Loads libmidd.so once; raises NativeLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeLibraryError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C medical-image-denoising-using-diffusion_amd/csrc`). "
+                    "This package has no CPU fallback.")
+            try:
+                handle = C.CDLL(LIB_PATH)
+            except OSError as exc:
+                raise NativeLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+            for name, restype, argtypes in SYMBOLS:
+                fn = getattr(handle, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MiddError(rc, lib().mi_last_error().decode("utf-8", "replace"))
