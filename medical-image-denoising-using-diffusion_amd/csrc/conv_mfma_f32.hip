@@ -249,7 +249,7 @@ bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTil
         if (nn % cand == 0) { wn = cand; break; }
     // candidates with this (nt, wn): choose the largest pixel tile that still yields >= 2 workgroups per CU
     const TileDesc* best = nullptr;
-    long best_score = -1;
+    long best_score = -(1L << 60);
     for (const TileDesc& d : kTiles) {
         if (d.nt != nt || d.wn != wn) continue;
         const int bm = d.wm * d.mt * 16, th = bm / d.tw;
