@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the reverse-diffusion sampler path on MI355X.
+
+Contract (task statement): ``python bench.py --gpus N --steps K --warmup W`` — one "step" is one
+pass of the hot path over one batch: ``DiffusionDenoiser.denoise`` of B images through the
+50-iteration reverse loop (BASELINE.json configs[1]: batch 8, 256x256, 50 steps, one MI355X).
+For N > 1 it is launched by torch.distributed.run, one rank per GPU; the batch is sharded
+(B per GPU fixed -> weak scaling) and one RCCL all-gather collects the outputs.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import midd_loader  # noqa: E402
+
+midd_loader.load()
+from midd_amd import UNetDiffusion, DiffusionDenoiser, UNetConfig, topology, timestep_list  # noqa: E402
+from midd_amd.sharding import gather_outputs  # noqa: E402
+from midd_amd.weights import make_state_dict, synthetic_xray  # noqa: E402
+
+# Work model, SURVEY.md section 8(d): reference-graph FLOPs and ideal-fusion bytes per image-step.
+GF_PER_IMAGE_STEP = {256: 91.669e9, 512: 424.656e9}
+BYTES_PER_IMAGE_STEP_F32 = {256: 846.2e6, 512: 3384.8e6}
+PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_HBM = 8.0e12
+
+
+def cpu_baseline(sd_np, cfg, size, noise_steps, iters):
+    """The oracle (a port of the reference's CPU path, pinned against it in the build container)
+    timed on this host's cores on a bounded sample: 1 image, `iters` of the 50 iterations."""
+    from oracle import ddim_oracle as orc
+    sd = orc.to_torch(sd_np)
+    topo = topology(cfg)
+    noisy = torch.from_numpy(synthetic_xray(1, size, size, seed=1234))
+    beta, alpha, alpha_hat = orc.schedule(noise_steps)
+    steps = timestep_list(noise_steps, noise_steps)[:iters]
+    x = noisy.clone()
+    with torch.no_grad():
+        orc.unet_forward(sd, topo, x, noisy, torch.tensor([steps[0]]))      # warm-up (thread pool, oneDNN primitives)
+        t0 = time.perf_counter()
+        for i in steps:
+            t = torch.full((1,), i, dtype=torch.long)
+            eps = torch.clamp(orc.unet_forward(sd, topo, x, noisy, t), -5, 5)
+            a, ah = alpha[t][:, None, None, None], alpha_hat[t][:, None, None, None]
+            x = torch.clamp((1 / torch.sqrt(a)) * (x - ((1 - a) / torch.sqrt(1 - ah)) * eps), 0, 1)
+        dt = time.perf_counter() - t0
+    per_iter = dt / len(steps)
+    return x, steps, dict(value=1.0 / (per_iter * noise_steps), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                          sample=f"1 image {size}x{size}, {len(steps)} of {noise_steps} iterations in {dt:.1f} s, "
+                                 f"torch {torch.__version__} CPU fp32 oracle (oracle/ddim_oracle.py)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--inference-steps", type=int, default=50)
+    ap.add_argument("--noise-steps", type=int, default=50)
+    ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sampler path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)        # "nccl" is RCCL on ROCm
+
+    cfg = UNetConfig()
+    sd_np = make_state_dict(cfg, seed=42)                     # random-init weights of the architecture
+    model = UNetDiffusion()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model = model.to(dev).eval()
+    den = DiffusionDenoiser(model, noise_steps=args.noise_steps)
+    Bp, S = args.batch_per_gpu, args.size
+    # inputs resident in HBM before the timed region; image seeds continue across ranks
+    noisy = torch.from_numpy(synthetic_xray(Bp, S, S, seed=1234 + rank * Bp)).to(dev)
+    n_iters = len(timestep_list(args.noise_steps, args.inference_steps))
+
+    def step():
+        out = den.denoise(noisy, inference_steps=args.inference_steps)
+        return gather_outputs(out) if world > 1 else out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert out.shape[0] == Bp * world and torch.isfinite(out).all()
+
+    images = Bp * world * args.steps
+    value = images / elapsed
+    result = {
+        "metric": "denoised images/sec, 256x256 x50 DDIM steps" if (S == 256 and n_iters == 50)
+                  else f"denoised images/sec, {S}x{S} x{n_iters} DDIM steps",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"batch={Bp}/GPU {S}x{S} grayscale, {n_iters}-iteration reverse loop "
+                               f"(noise_steps={args.noise_steps}, inference_steps={args.inference_steps}), "
+                               "random-init 12.8M-param UNet (BASELINE.json configs[1])",
+                   "batch_per_gpu": Bp, "global_batch": Bp * world, "image": [S, S], "iterations": n_iters,
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "collective": "one all_gather_into_tensor (RCCL) per step" if world > 1 else "none"},
+    }
+
+    if rank == 0:
+        # ---- roofline leg: per-kernel HIP-event timing of one more step on the same stream ----
+        model.profile_begin()
+        den.denoise(noisy, inference_steps=args.inference_steps)
+        prof = model.profile_end()
+        total_ms = sum(p["total_ms"] for p in prof)
+        dom = max((p for p in prof if p["flops"] > 0), key=lambda p: p["total_ms"])
+        achieved = dom["flops"] / (dom["total_ms"] * 1e-3)
+        result["roofline"] = {
+            "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_F32 / 1e12,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32, "traffic": None,
+            "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
+            "alg_flops_per_launch": dom["flops"] / dom["launches"],
+            "share_of_kernel_time": dom["total_ms"] / total_ms,
+        }
+        gf = GF_PER_IMAGE_STEP.get(S)
+        if gf:
+            per_gpu_rate = (value / world) * n_iters          # image-steps per second per GPU
+            result["whole_loop"] = {
+                "ref_graph_tflops": per_gpu_rate * gf / 1e12, "frac_mfma_f32_peak": per_gpu_rate * gf / PEAK_MFMA_F32,
+                "alg_GBps": per_gpu_rate * BYTES_PER_IMAGE_STEP_F32[S] / 1e9,
+                "frac_hbm_peak": per_gpu_rate * BYTES_PER_IMAGE_STEP_F32[S] / PEAK_HBM,
+            }
+        result["kernels"] = sorted(
+            [dict(name=p["name"], launches=p["launches"], ms=round(p["total_ms"], 3),
+                  tflops=round(p["flops"] / (p["total_ms"] * 1e-3) / 1e12, 2) if p["flops"] else None,
+                  GBps=round(p["bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1)) for p in prof],
+            key=lambda d: -d["ms"])[:8]
+
+        # ---- CPU baseline (rank 0, N = 1 only) + a parity spot check on the same sample ----
+        if world == 1 and args.cpu_iters > 0 and S <= 512:
+            x_cpu, steps, base = cpu_baseline(sd_np, cfg, S, args.noise_steps, args.cpu_iters)
+            result["cpu_baseline"] = base
+            one = torch.from_numpy(synthetic_xray(1, S, S, seed=1234)).to(dev)
+            x_gpu = model.run_sampler(one, steps, den.beta, den.alpha, den.alpha_hat, clamp_eps=True)
+            result["parity_max_abs_err_vs_oracle"] = float((x_gpu.cpu() - x_cpu).abs().max())
+            result["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,8 +116,23 @@ int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, in
 int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int H, int W,
                    const void* workspace, float* dst, int* C, int* h, int* w, void* stream);
 
-/* Kernel-level timing of the last mi_denoise/mi_unet_forward... is left to HIP events /
- * rocprofv3 on the caller's stream. */
+/* Per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg; the
+ * reference's only timer for this path is time.time() around denoise(), DDIMModel.py:495-498).
+ * Between mi_profile_begin and mi_profile_end every kernel launched by mi_unet_forward /
+ * mi_denoise on this plan is bracketed by an event pair.  mi_profile_end synchronises the
+ * recorded events and returns one entry per distinct kernel symbol: launches, summed
+ * duration, and the ALGORITHMIC work of those launches (flops = 2*MACs of the contraction the
+ * launch performs; bytes = the tensors it must read + write once, fp32).  Calls made while
+ * profiling must not be issued concurrently from several threads. */
+typedef struct mi_profile_entry {
+    char   name[128];      /* kernel symbol as rocprofv3 prints it (without "void " / argument list) */
+    int64_t launches;
+    double total_ms;
+    double flops;          /* summed over the launches */
+    double bytes;
+} mi_profile_entry;
+int mi_profile_begin(mi_plan* plan);
+int mi_profile_end(mi_plan* plan, mi_profile_entry* out, int max_entries, int* n_entries);
 
 void mi_plan_destroy(mi_plan* plan);
 

@@ -94,6 +94,11 @@ struct mi_plan {
     int device = -1;
     std::mutex mu;
     std::map<uint64_t, std::unique_ptr<Program>> programs;
+    // profiling (mi_profile_begin/end)
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; std::string name; double flops, bytes; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
 };
 
 static bool is_attn_level(const mi_unet_cfg& c, int i) {
@@ -602,12 +607,70 @@ struct StepIO {
     float* x_update; const float* noise; float c1, c2, c3; int clamp_eps;
 };
 
+// Kernel symbol + algorithmic work of one op (for mi_profile_*).
+static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, double* flops, double* bytes) {
+    const double B = g->B;
+    char buf[128];
+    auto elems = [&](const TensorRef& t) { return B * t.H * t.W * t.C; };
+    switch (o.kind) {
+        case OP_IN_CONV:
+            *name = "midd::in_conv_kernel";
+            *flops = 2.0 * B * g->H * g->W * o.dst.C * 9 * 2 * p->cfg.in_channels;
+            *bytes = 4.0 * (2.0 * B * p->cfg.in_channels * g->H * g->W + elems(o.dst));
+            break;
+        case OP_GN:
+            *name = "midd::gn_partial_kernel+gn_finalize_kernel";
+            *flops = 0; *bytes = 4.0 * (elems(o.s0) + (o.has_s1 ? elems(o.s1) : 0));
+            break;
+        case OP_CONV: {
+            snprintf(buf, sizeof(buf), "midd::conv_mfma_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", o.tile.ks, o.tile.stride,
+                     o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn);
+            *name = buf;
+            const double cin = o.s0.C + (o.has_s1 ? o.s1.C : 0);
+            *flops = 2.0 * elems(o.dst) * cin * o.ks * o.ks;
+            *bytes = 4.0 * (elems(o.s0) + (o.has_s1 ? elems(o.s1) : 0) + elems(o.dst) + (o.has_resid ? elems(o.resid) : 0)
+                            + (double)o.dst.C * cin * o.ks * o.ks);
+            break;
+        }
+        case OP_ATTN: {
+            const double N = (double)o.dst.H * o.dst.W;
+            snprintf(buf, sizeof(buf), "midd::attention_f32_kernel<%d>", o.dst.C / 2);
+            *name = buf;
+            *flops = 4.0 * B * N * N * o.dst.C;              // QK^T + PV over both heads
+            *bytes = 4.0 * (elems(o.s0) + elems(o.dst));
+            break;
+        }
+        case OP_RESIZE: *name = "midd::resize_bilinear_kernel"; *flops = 0; *bytes = 4.0 * (elems(o.s0) + elems(o.dst)); break;
+        case OP_CONVT:
+            *name = "midd::conv_transpose_kernel";
+            *flops = 2.0 * elems(o.s0) * o.dst.C * 16; *bytes = 4.0 * (elems(o.s0) + elems(o.dst));
+            break;
+        case OP_OUT:
+            *name = "midd::out_conv_kernel";
+            *flops = 2.0 * B * g->H * g->W * o.s0.C * 9 * p->cfg.in_channels;
+            *bytes = 4.0 * (elems(o.s0) + 3.0 * B * p->cfg.in_channels * g->H * g->W);
+            break;
+    }
+}
+
 static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s) {
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
     for (const Op& o : g->ops) {
         hipError_t e = hipSuccess;
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        if (p->profiling) {
+            auto take = [&]() -> hipEvent_t {
+                hipEvent_t ev = nullptr;
+                if (!p->event_pool.empty()) { ev = p->event_pool.back(); p->event_pool.pop_back(); }
+                else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+                return ev;
+            };
+            ev_a = take(); ev_b = take();
+            if (!ev_a || !ev_b) return fail(MI_EHIP, "hipEventCreate failed");
+            (void)hipEventRecord(ev_a, s);
+        }
         switch (o.kind) {
             case OP_IN_CONV:
                 e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), B, p->cfg.in_channels,
@@ -658,6 +721,12 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             }
         }
         if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
+        if (p->profiling) {
+            (void)hipEventRecord(ev_b, s);
+            mi_plan::Span sp; sp.a = ev_a; sp.b = ev_b;
+            op_work(p, g, o, &sp.name, &sp.flops, &sp.bytes);
+            p->spans.push_back(std::move(sp));
+        }
     }
     return MI_OK;
 }
@@ -742,8 +811,43 @@ extern "C" int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int
     return MI_OK;
 }
 
+extern "C" int mi_profile_begin(mi_plan* plan) {
+    if (!plan) return fail(MI_EINVAL, "null plan");
+    for (auto& sp : plan->spans) { plan->event_pool.push_back(sp.a); plan->event_pool.push_back(sp.b); }
+    plan->spans.clear();
+    plan->profiling = true;
+    return MI_OK;
+}
+
+extern "C" int mi_profile_end(mi_plan* plan, mi_profile_entry* out, int max_entries, int* n_entries) {
+    if (!plan || !n_entries) return fail(MI_EINVAL, "null argument");
+    plan->profiling = false;
+    std::map<std::string, mi_profile_entry> agg;
+    std::vector<std::string> order;
+    for (auto& sp : plan->spans) {
+        HIPCHK(hipEventSynchronize(sp.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, sp.a, sp.b));
+        auto it = agg.find(sp.name);
+        if (it == agg.end()) {
+            mi_profile_entry e{};
+            snprintf(e.name, sizeof(e.name), "%s", sp.name.c_str());
+            it = agg.emplace(sp.name, e).first;
+            order.push_back(sp.name);
+        }
+        it->second.launches += 1; it->second.total_ms += ms; it->second.flops += sp.flops; it->second.bytes += sp.bytes;
+        plan->event_pool.push_back(sp.a); plan->event_pool.push_back(sp.b);
+    }
+    plan->spans.clear();
+    *n_entries = (int)order.size();
+    for (int i = 0; i < (int)order.size() && i < max_entries && out; ++i) out[i] = agg[order[i]];
+    return MI_OK;
+}
+
 extern "C" void mi_plan_destroy(mi_plan* plan) {
     if (!plan) return;
+    for (auto& sp : plan->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t ev : plan->event_pool) (void)hipEventDestroy(ev);
     if (plan->wdev) (void)hipFree(plan->wdev);
     if (plan->ttab) (void)hipFree(plan->ttab);
     delete plan;

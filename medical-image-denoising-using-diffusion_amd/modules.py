@@ -224,6 +224,21 @@ class UNetDiffusion(nn.Module):
                                             torch.cuda.current_stream(dev).cuda_stream))
         return out
 
+    def profile_begin(self) -> None:
+        """Bracket every kernel of subsequent calls with HIP events (bench.py roofline leg)."""
+        with self._lock:
+            self._ensure_plan()
+            native.check(native.lib().mi_profile_begin(self._plan))
+
+    def profile_end(self):
+        """-> list of dicts {name, launches, total_ms, flops, bytes}, one per kernel symbol."""
+        with self._lock:
+            buf = (native.ProfileEntry * 64)()
+            n = C.c_int()
+            native.check(native.lib().mi_profile_end(self._plan, buf, 64, C.byref(n)))
+            return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
+                         flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(min(n.value, 64))]
+
     def workspace_bytes(self, B: int, H: int, W: int) -> int:
         with self._lock, torch.cuda.device(self._device()):
             self._ensure_plan()

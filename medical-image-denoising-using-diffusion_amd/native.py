@@ -34,6 +34,11 @@ class UNetCfg(C.Structure):
                 ("time_emb_dim", C.c_int32), ("variant", C.c_int32)]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 # every symbol include/midd.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("mi_unet_plan_create", C.c_int, [C.POINTER(UNetCfg), C.POINTER(C.c_void_p)]),
@@ -49,6 +54,8 @@ SYMBOLS = [
                              C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mi_debug_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    ("mi_profile_begin", C.c_int, [C.c_void_p]),
+    ("mi_profile_end", C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     ("mi_plan_destroy", None, [C.c_void_p]),
     ("mi_last_error", C.c_char_p, []),
     ("mi_version", C.c_char_p, []),
