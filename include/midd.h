@@ -43,6 +43,11 @@ extern "C" {
 #define MI_VARIANT_DDIM  0   /* Backend/DDIM/DDIMModel.py  */
 #define MI_VARIANT_CDDPM 1   /* Backend/cddpm/cddpmModels.py */
 
+/* arithmetic of the MFMA contractions (convolutions, attention) */
+#define MI_COMPUTE_F32   0   /* fp32-input MFMA: bit-for-bit an fp32 fma chain */
+#define MI_COMPUTE_F16X3 1   /* fp32 operands split into two fp16 halves, three fp16 MFMAs, fp32 accumulate
+                                (~2^-21 relative per product; same parity gate) — about 5x the MFMA rate */
+
 /* sampler flags for mi_denoise */
 #define MI_CLAMP_EPS     1   /* clamp(eps,-5,5) before the update: DDIMModel.py:278 (absent in cddpm) */
 
@@ -59,6 +64,7 @@ typedef struct mi_unet_cfg {
     int32_t attention_levels[MI_MAX_LEVELS];     /* (3,) — level indices */
     int32_t time_emb_dim;                        /* 192 */
     int32_t variant;                             /* MI_VARIANT_* */
+    int32_t compute_mode;                        /* MI_COMPUTE_* (not a reference argument) */
 } mi_unet_cfg;
 
 /* Replaces UNetDiffusion.__init__ (DDIMModel.py:169-217): derives the module lists

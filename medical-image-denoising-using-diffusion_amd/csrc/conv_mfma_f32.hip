@@ -187,6 +187,9 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
 
     // ---- epilogue: bias (+ time embedding) (+ residual), NHWC float4 stores --------------
     const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
+    f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = (ntile0 + nt) * 16 + kq * 4;
@@ -203,6 +206,27 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
                 f32x4 v = acc[mt][nt] + add;
                 if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
                 *reinterpret_cast<f32x4*>(a.out + o) = v;
+                ssum[nt] += v; ssq[nt] += v * v;
+            }
+        }
+    }
+    if (a.stat_partial != nullptr) {
+        // per-channel partial sums of the output for the next GroupNorm (see conv_mfma_f16x3.hip)
+        const int row = trem * WM + wm;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = ssum[nt][e], s2 = ssq[nt][e];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+                ssum[nt][e] = s1; ssq[nt][e] = s2;
+            }
+            if (p16 == 0) {
+                const int co = (ntile0 + nt) * 16 + kq * 4;
+                float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
+                *reinterpret_cast<f32x4*>(pr) = ssum[nt];
+                *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
             }
         }
     }
@@ -252,6 +276,7 @@ bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTil
     long best_score = -(1L << 60);
     for (const TileDesc& d : kTiles) {
         if (d.nt != nt || d.wn != wn) continue;
+        if (stride == 2 && d.mt > 2) continue;
         const int bm = d.wm * d.mt * 16, th = bm / d.tw;
         const long wgs = (long)B * ((OW + d.tw - 1) / d.tw) * ((OH + th - 1) / th) * (Cout / (wn * nt * 16));
         // padding waste of ragged tiles counts against a tile

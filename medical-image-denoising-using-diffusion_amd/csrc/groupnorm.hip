@@ -111,6 +111,116 @@ int gn_pick_nsplit(int B, int HW, int C) {
     return ns;
 }
 
+// ------------------------------------------------------------------------------ fused-statistics path
+// Per-channel partial sums [B][rows][2][C] come from the producing convolution's epilogue
+// (conv_mfma_*.hip) or, for tensors no MFMA conv produced (in_conv output, bilinear 2x
+// outputs), from chan_partial_kernel.  gn_from_partial_kernel folds them in a fixed order in
+// fp64 and emits scale/shift; one block per (group, sample).  Channels are resolved one by one
+// to (source, local channel), so groups may straddle the torch.cat seam (cddpm up path).
+__global__ __launch_bounds__(GN_THREADS)
+void gn_from_partial_kernel(const GnFromPartialArgs a) {
+    __shared__ double red[GN_THREADS][2];
+    __shared__ float s_mr[2];
+    const int C = a.C0 + a.C1;
+    const int cg = C / GN_GROUPS_;
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int nrl = GN_THREADS / cg;                  // row lanes
+    const int ci = tid % cg, rl = tid / cg;
+    double s1 = 0, s2 = 0;
+    if (rl < nrl) {
+        const int c = g * cg + ci;
+        const float* p; int rows, Cs, cl;
+        if (c < a.C0) { p = a.part0; rows = a.rows0; Cs = a.C0; cl = c; }
+        else          { p = a.part1; rows = a.rows1; Cs = a.C1; cl = c - a.C0; }
+        p += (size_t)b * rows * 2 * Cs + cl;
+        for (int r = rl; r < rows; r += nrl) {
+            s1 += (double)p[(size_t)r * 2 * Cs];
+            s2 += (double)p[(size_t)r * 2 * Cs + Cs];
+        }
+    }
+    red[tid][0] = s1; red[tid][1] = s2;
+    __syncthreads();
+    if (tid < cg) {                                    // fold row lanes, fixed order
+        double t1 = 0, t2 = 0;
+        for (int l = 0; l < nrl; ++l) { t1 += red[l * cg + tid][0]; t2 += red[l * cg + tid][1]; }
+        red[tid][0] = t1; red[tid][1] = t2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double t1 = 0, t2 = 0;
+        for (int c = 0; c < cg; ++c) { t1 += red[c][0]; t2 += red[c][1]; }
+        const double n = (double)a.HW * cg;
+        const double mean = t1 / n;
+        double var = t2 / n - mean * mean;
+        if (var < 0) var = 0;
+        s_mr[0] = (float)mean;
+        s_mr[1] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+    __syncthreads();
+    if (tid < cg) {
+        const int c = g * cg + tid;
+        const float sc = s_mr[1] * a.gamma[c];
+        a.scale[(size_t)b * C + c] = sc;
+        a.shift[(size_t)b * C + c] = a.beta[c] - s_mr[0] * sc;
+    }
+}
+
+hipError_t gn_from_partial_launch(const GnFromPartialArgs& a, hipStream_t s) {
+    const int C = a.C0 + a.C1;
+    if (C % GN_GROUPS_ || C / GN_GROUPS_ > GN_THREADS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_from_partial_kernel, dim3(GN_GROUPS_, a.B), dim3(GN_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(GN_THREADS)
+void chan_partial_kernel(const float* __restrict__ src, float* __restrict__ part, int HW, int C, int rows) {
+    extern __shared__ double red[];               // [ppi][C][2]
+    const int CQ = C >> 2;
+    const int ppi = GN_THREADS / CQ;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, row = blockIdx.x;
+    const int pl = tid / CQ, q = tid - pl * CQ;
+    const int per = (HW + rows - 1) / rows;
+    const int p0 = row * per, p1 = min(HW, p0 + per);
+    if (pl < ppi) {
+        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+        const float* base = src + (size_t)b * HW * C + q * 4;
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; ss[e] = fma(d, d, ss[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[((size_t)pl * C + q * 4 + e) * 2 + 0] = s[e];
+            red[((size_t)pl * C + q * 4 + e) * 2 + 1] = ss[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += GN_THREADS) {
+        double cs = 0, css = 0;
+        for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
+        float* o = part + ((size_t)(b * rows + row) * 2) * C + c;
+        o[0] = (float)cs; o[C] = (float)css;
+    }
+}
+
+int chan_partial_rows(int HW, int C) {
+    const int ppi = GN_THREADS / (C / 4);
+    int r = HW / (ppi * 8);
+    if (r < 1) r = 1;
+    if (r > 128) r = 128;
+    return r;
+}
+
+hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int C, int rows, hipStream_t s) {
+    if (C % 4 || C / 4 > GN_THREADS) return hipErrorInvalidValue;
+    const int ppi = GN_THREADS / (C / 4);
+    const size_t lds = (size_t)ppi * C * 2 * sizeof(double);
+    hipLaunchKernelGGL(chan_partial_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, part, HW, C, rows);
+    return hipGetLastError();
+}
+
 hipError_t gn_stats_launch(const GnArgs& a, hipStream_t s) {
     const int C = a.C0 + a.C1;
     if (C % 8 || C / 4 > GN_THREADS) return hipErrorInvalidValue;    // 8 groups, float4 loads

@@ -50,13 +50,17 @@ struct Mod {
     size_t g1 = 0, be1 = 0, g2 = 0, be2 = 0;                      // rb / attn GroupNorm affine
     size_t wq = 0, bq = 0, wp = 0, bp = 0;                        // attn: qkv, proj
     size_t wc = 0, bc = 0, wt = 0;                                // down / up(folded 3x3) conv, raw ConvT
+    float s1 = 1.f, s2 = 1.f, sr = 1.f, sq = 1.f, sp = 1.f, sc = 1.f;   // f16x3 output scales of the convs above
 };
 
 struct HostWeight { std::vector<int64_t> shape; std::vector<float> data; bool loaded = false; };
 
-struct TensorRef { size_t off = 0; int C = 0, H = 0, W = 0; };
+struct TensorRef {
+    size_t off = 0; int C = 0, H = 0, W = 0;
+    size_t stat_off = (size_t)-1; int stat_rows = 0;       // per-channel partial sums [B][rows][2][C], if produced
+};
 
-enum OpKind { OP_IN_CONV, OP_GN, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT };
+enum OpKind { OP_IN_CONV, OP_GN, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_PART };
 struct Op {
     OpKind kind;
     // sources / destination (workspace offsets in bytes)
@@ -70,6 +74,8 @@ struct Op {
     int prologue = PRO_RAW, temb_col = -1;
     ConvTile tile{};
     int stride = 1, ks = 3;
+    bool want_stats = false;
+    float out_scale = 1.f;
 };
 
 struct Program {
@@ -205,7 +211,7 @@ static int build_topology(mi_plan* p) {
 
 // ------------------------------------------------------------------------------ C ABI: create / load
 extern "C" const char* mi_last_error(void) { return g_err; }
-extern "C" const char* mi_version(void) { return "midd 0.1 gfx950 fp32-mfma"; }
+extern "C" const char* mi_version(void) { return "midd 0.2 gfx950 (fp32 MFMA | split-fp16 x3 MFMA)"; }
 
 extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
     if (!cfg || !out) return fail(MI_EINVAL, "null argument");
@@ -216,6 +222,7 @@ extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
     if (cfg->num_res_blocks < 1) return fail(MI_EINVAL, "num_res_blocks must be >= 1");
     if (cfg->time_emb_dim < 1) return fail(MI_EINVAL, "time_emb_dim must be >= 1");
     if (cfg->variant != MI_VARIANT_DDIM && cfg->variant != MI_VARIANT_CDDPM) return fail(MI_EINVAL, "unknown variant %d", cfg->variant);
+    if (cfg->compute_mode != MI_COMPUTE_F32 && cfg->compute_mode != MI_COMPUTE_F16X3) return fail(MI_EINVAL, "unknown compute_mode %d", cfg->compute_mode);
     for (int i = 0; i < cfg->num_levels; ++i)
         if (cfg->channel_mult[i] < 1) return fail(MI_EINVAL, "channel_mult[%d] must be >= 1", i);
     for (int i = 0; i < cfg->num_attention_levels; ++i) {
@@ -274,7 +281,7 @@ struct Packer {
 // torch Conv2d weight [Cout][Cin][KS][KS]  ->  [Cin/16][KS*KS][Cout/16][lane 64][4]
 // lane = kq*16 + n holds W[cout = 16*tile + n][cin = 16*chunk + 4*kq + j][tap] in element j:
 // the A-operand fragment order of conv_mfma_f32.hip.
-static std::vector<float> pack_conv(const float* w, int Cout, int Cin, int KS) {
+static std::vector<float> pack_conv_f32(const float* w, int Cout, int Cin, int KS) {
     const int taps = KS * KS, nch = Cin / 16, ntile = Cout / 16;
     std::vector<float> out((size_t)nch * taps * ntile * 256);
     for (int c = 0; c < nch; ++c)
@@ -289,6 +296,56 @@ static std::vector<float> pack_conv(const float* w, int Cout, int Cin, int KS) {
                     }
                 }
     return out;
+}
+
+// Split-fp16 packing for conv_mfma_f16x3.hip:  [step][Cout/16][hi|lo][lane 64][8 fp16].
+// Steps walk 32 input channels (blocks 2c, 2c+1) per tap; a trailing single block pairs two
+// taps per step.  lane = kq*16 + n; element j is W[16*tile+n][cin][tap] with
+//   full chunk : cin = 16*(2c + (kq>>1)) + 8*(kq&1) + j, tap = step's tap
+//   half chunk : cin = 16*(2c) + 8*(kq&1) + j,           tap = 2*hs + (kq>>1)  (zero when >= taps)
+// w' = w * 2^k (k per layer, max|w'| in [2^13,2^14)); hi = fp16(w'), lo = fp16(w' - hi).
+// *out_scale = 2^-k / ACT_PRESCALE.  Returned as raw 32-bit words (two fp16 each).
+static const float ACT_PRESCALE_H = 16.0f;      // 2^s: must match ACT_PRESCALE in conv_mfma_f16x3.hip
+static std::vector<float> pack_conv_f16x3(const float* w, int Cout, int Cin, int KS, float* out_scale) {
+    const int taps = KS * KS, nblk = Cin / 16, ntile = Cout / 16;
+    const int steps = conv16_num_steps(Cin, taps);
+    float wmax = 0.f;
+    for (size_t i = 0; i < (size_t)Cout * Cin * taps; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+    int e = 0;
+    if (wmax > 0.f) (void)std::frexp(wmax, &e);          // wmax = m * 2^e, m in [0.5, 1)
+    const int k = 14 - e;                                // max|w * 2^k| in [2^13, 2^14)
+    const float wscale = std::ldexp(1.0f, k);
+    *out_scale = std::ldexp(1.0f, -k) / ACT_PRESCALE_H;
+    std::vector<_Float16> out((size_t)steps * ntile * 2 * 64 * 8);
+    int step = 0;
+    auto emit = [&](int blk_of_kq0, int blk_of_kq2, int tap_of_kq0, int tap_of_kq2) {
+        for (int nt = 0; nt < ntile; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int n = lane & 15, kq = lane >> 4;
+                const int blk = (kq >> 1) ? blk_of_kq2 : blk_of_kq0;
+                const int tap = (kq >> 1) ? tap_of_kq2 : tap_of_kq0;
+                for (int j = 0; j < 8; ++j) {
+                    float v = 0.f;
+                    if (tap < taps) {
+                        const int co = nt * 16 + n, ci = blk * 16 + 8 * (kq & 1) + j;
+                        v = w[((size_t)co * Cin + ci) * taps + tap] * wscale;
+                    }
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const size_t base = (((size_t)step * ntile + nt) * 2) * 64 * 8;
+                    out[base + (size_t)lane * 8 + j] = hi;
+                    out[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+                }
+            }
+        ++step;
+    };
+    for (int c = 0; 2 * c < nblk; ++c) {
+        if (2 * c + 1 < nblk) for (int t = 0; t < taps; ++t) emit(2 * c, 2 * c + 1, t, t);
+        else for (int hs = 0; hs < (taps + 1) / 2; ++hs) emit(2 * c, 2 * c, 2 * hs, 2 * hs + 1);
+    }
+    std::vector<float> words(out.size() / 2);
+    memcpy(words.data(), out.data(), out.size() * sizeof(_Float16));
+    return words;
 }
 
 // ConvTranspose2d(4,2,1) followed by the bilinear half-size resample (an exact 2x2 mean for
@@ -368,31 +425,36 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
         if (!getw(plan, k)) return fail(MI_ESTATE, "missing key in state_dict: \"%s\"", k.c_str());
 
     Packer pk;
+    const bool f16 = plan->cfg.compute_mode == MI_COMPUTE_F16X3;
+    auto pack_conv = [&](const float* w, int Cout, int Cin, int KS, float* scale) {
+        *scale = 1.0f;
+        return f16 ? pack_conv_f16x3(w, Cout, Cin, KS, scale) : pack_conv_f32(w, Cout, Cin, KS);
+    };
     auto W = [&](const std::string& k) { return getw(plan, k)->data.data(); };
     auto put_raw = [&](const std::string& k) { return pk.put(getw(plan, k)->data); };
     auto pack_mod = [&](Mod& m) {
         switch (m.kind) {
             case MOD_RB:
                 m.g1 = put_raw(m.name + ".block1.0.weight"); m.be1 = put_raw(m.name + ".block1.0.bias");
-                m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3)); m.b1 = put_raw(m.name + ".block1.2.bias");
+                m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3, &m.s1)); m.b1 = put_raw(m.name + ".block1.2.bias");
                 m.g2 = put_raw(m.name + ".block2.0.weight"); m.be2 = put_raw(m.name + ".block2.0.bias");
-                m.w2 = pk.put(pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3)); m.b2 = put_raw(m.name + ".block2.3.bias");
+                m.w2 = pk.put(pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3, &m.s2)); m.b2 = put_raw(m.name + ".block2.3.bias");
                 if (m.in_c != m.out_c) {
-                    m.wr = pk.put(pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1)); m.br = put_raw(m.name + ".res_conv.bias");
+                    m.wr = pk.put(pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1, &m.sr)); m.br = put_raw(m.name + ".res_conv.bias");
                 }
                 break;
             case MOD_ATTN:
                 m.g1 = put_raw(m.name + ".norm.weight"); m.be1 = put_raw(m.name + ".norm.bias");
-                m.wq = pk.put(pack_conv(W(m.name + ".qkv.weight"), 3 * m.in_c, m.in_c, 1)); m.bq = put_raw(m.name + ".qkv.bias");
-                m.wp = pk.put(pack_conv(W(m.name + ".proj.weight"), m.in_c, m.in_c, 1)); m.bp = put_raw(m.name + ".proj.bias");
+                m.wq = pk.put(pack_conv(W(m.name + ".qkv.weight"), 3 * m.in_c, m.in_c, 1, &m.sq)); m.bq = put_raw(m.name + ".qkv.bias");
+                m.wp = pk.put(pack_conv(W(m.name + ".proj.weight"), m.in_c, m.in_c, 1, &m.sp)); m.bp = put_raw(m.name + ".proj.bias");
                 break;
             case MOD_DOWN:
-                m.wc = pk.put(pack_conv(W(m.name + ".weight"), m.out_c, m.in_c, 3)); m.bc = put_raw(m.name + ".bias");
+                m.wc = pk.put(pack_conv(W(m.name + ".weight"), m.out_c, m.in_c, 3, &m.sc)); m.bc = put_raw(m.name + ".bias");
                 break;
             case MOD_UP: {
                 const float* w = W(m.name + ".weight");
                 std::vector<float> eff = fold_convt(w, m.in_c, m.out_c);
-                m.wc = pk.put(pack_conv(eff.data(), m.out_c, m.in_c, 3)); m.bc = put_raw(m.name + ".bias");
+                m.wc = pk.put(pack_conv(eff.data(), m.out_c, m.in_c, 3, &m.sc)); m.bc = put_raw(m.name + ".bias");
                 // raw layout [ky][kx][Cin][Cout] for the direct fallback kernel
                 std::vector<float> raw((size_t)16 * m.in_c * m.out_c);
                 for (int ci = 0; ci < m.in_c; ++ci) for (int co = 0; co < m.out_c; ++co)
@@ -451,26 +513,39 @@ struct Builder {
         t.off = bump.take((size_t)B * H * W * C * sizeof(float));
         return t;
     }
-    // GroupNorm statistics op; returns its index so consumers can find scale/shift
+    // per-channel partial sums for a tensor no MFMA convolution produced
+    void ensure_stats(TensorRef& t) {
+        if (t.stat_off != (size_t)-1) return;
+        t.stat_rows = chan_partial_rows(t.H * t.W, t.C);
+        t.stat_off = bump.take((size_t)B * t.stat_rows * 2 * t.C * sizeof(float));
+        Op o{}; o.kind = OP_CHAN_PART; o.s0 = t; g->ops.push_back(o);
+    }
+    // GroupNorm scale/shift from the producers' partial sums; returns the op index
     int gn(const TensorRef& s0, const TensorRef* s1, size_t gamma, size_t beta) {
         Op o{}; o.kind = OP_GN; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
         const int C = s0.C + (s1 ? s1->C : 0);
         o.gamma = gamma; o.beta = beta;
-        o.nsplit = gn_pick_nsplit(B, s0.H * s0.W, C);
         o.scale_off = bump.take((size_t)B * C * sizeof(float));
         o.shift_off = bump.take((size_t)B * C * sizeof(float));
-        o.partial_off = bump.take((size_t)B * o.nsplit * 16 * sizeof(double));
         g->ops.push_back(o);
         return (int)g->ops.size() - 1;
     }
-    int conv(const TensorRef& s0, const TensorRef* s1, const TensorRef& dst, size_t w, size_t b, int ks, int stride,
-             int prologue, int gn_op, int temb_col, const TensorRef* resid) {
-        Op o{}; o.kind = OP_CONV; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
-        o.dst = dst; o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
+    int conv(const TensorRef& s0, const TensorRef* s1, TensorRef& dst, size_t w, size_t b, float wscale, int ks, int stride,
+             int prologue, int gn_op, int temb_col, const TensorRef* resid, bool want_stats) {
+        Op o{}; o.kind = OP_CONV; o.out_scale = wscale; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
+        o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
         if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
         if (resid) { o.resid = *resid; o.has_resid = true; }
-        if (!conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile))
-            return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
+        const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
+                            ? conv16_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
+                            : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
+        if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
+        if (want_stats) {
+            dst.stat_rows = conv_stat_rows(o.tile, dst.H, dst.W);
+            dst.stat_off = bump.take((size_t)B * dst.stat_rows * 2 * dst.C * sizeof(float));
+            o.want_stats = true;
+        }
+        o.dst = dst;
         g->ops.push_back(o);
         return MI_OK;
     }
@@ -491,15 +566,16 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         if (cin != m.in_c) return fail(MI_EINVAL, "%s: expected %d input channels, graph provides %d", m.name.c_str(), m.in_c, cin);
         const int g1 = bld.gn(s0, s1, m.g1, m.be1);
         TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
-        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, 3, 1, PRO_GN_SILU, g1, m.temb_col, nullptr))) return rc;
+        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, g1, m.temb_col, nullptr, true))) return rc;
         const int g2 = bld.gn(h1, nullptr, m.g2, m.be2);
         TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
         if (m.in_c != m.out_c) {
-            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, 1, 1, PRO_RAW, -1, -1, nullptr))) return rc;   // res_conv(x)
-            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, 3, 1, PRO_GN_SILU, g2, -1, &o))) return rc;   // + in place
+            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, -1, -1, nullptr, false))) return rc;   // res_conv(x)
+            const TensorRef acc = o;
+            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &acc, true))) return rc;   // + in place
         } else {
             if (s1) return fail(MI_EINVAL, "%s: identity residual over a concatenated input", m.name.c_str());
-            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, 3, 1, PRO_GN_SILU, g2, -1, &s0))) return rc;
+            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &s0, true))) return rc;
         }
         *out = o;
         return MI_OK;
@@ -508,17 +584,18 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         const int C = x.C;
         const int gi = bld.gn(x, nullptr, m.g1, m.be1);
         TensorRef qkv = bld.alloc(3 * C, x.H, x.W);
-        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, 1, 1, PRO_GN, gi, -1, nullptr))) return rc;
+        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, gi, -1, nullptr, false))) return rc;
         TensorRef att = bld.alloc(C, x.H, x.W);
         Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = att; g->ops.push_back(o);
         TensorRef y = bld.alloc(C, x.H, x.W);
-        if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, 1, 1, PRO_RAW, -1, -1, &x))) return rc;
+        if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, m.sp, 1, 1, PRO_RAW, -1, -1, &x, true))) return rc;
         *out = y;
         return MI_OK;
     };
 
     TensorRef h = bld.alloc(c.model_channels, H, W);
     { Op o{}; o.kind = OP_IN_CONV; o.dst = h; g->ops.push_back(o); }
+    bld.ensure_stats(h);
     g->outputs["in_conv"] = h;
     std::vector<TensorRef> skips;
     for (const Mod& m : p->downs) {
@@ -527,7 +604,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         else if (m.kind == MOD_ATTN) { if ((rc = run_attn(m, h, &o))) return rc; }
         else {
             o = bld.alloc(m.out_c, h.H / 2, h.W / 2);     // 3x3 stride 2 pad 1 on even sizes
-            if ((rc = bld.conv(h, nullptr, o, m.wc, m.bc, 3, 2, PRO_RAW, -1, -1, nullptr))) return rc;
+            if ((rc = bld.conv(h, nullptr, o, m.wc, m.bc, m.sc, 3, 2, PRO_RAW, -1, -1, nullptr, true))) return rc;
         }
         h = o; skips.push_back(h); g->outputs[m.name] = h;       // every down module pushes a skip (DDIMModel.py:232)
     }
@@ -543,6 +620,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         TensorRef o = bld.alloc(pending_up->out_c, h.H * 2, h.W * 2);
         Op op{}; op.kind = OP_CONVT; op.s0 = h; op.dst = o; op.w = pending_up->wt; op.b = pending_up->bc;
         g->ops.push_back(op);
+        bld.ensure_stats(o);
         g->outputs[pending_up->name] = o;
         h = o; pending_up = nullptr;
         return MI_OK;
@@ -560,13 +638,14 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
             if (skip.H == h.H && skip.W == h.W) {
                 // ConvTranspose(4,2,1) then bilinear back to the skip's (half) size: one folded 3x3
                 TensorRef o = bld.alloc(pending_up->out_c, h.H, h.W);
-                if ((rc = bld.conv(h, nullptr, o, pending_up->wc, pending_up->bc, 3, 1, PRO_RAW, -1, -1, nullptr))) return rc;
+                if ((rc = bld.conv(h, nullptr, o, pending_up->wc, pending_up->bc, pending_up->sc, 3, 1, PRO_RAW, -1, -1, nullptr, true))) return rc;
                 h = o; pending_up = nullptr;
             } else if ((rc = flush_up())) return rc;
         }
         if (h.H != skip.H || h.W != skip.W) {                      // F.interpolate(..., bilinear) (DDIMModel.py:241-242)
             TensorRef o = bld.alloc(h.C, skip.H, skip.W);
             Op op{}; op.kind = OP_RESIZE; op.s0 = h; op.dst = o; g->ops.push_back(op);
+            bld.ensure_stats(o);
             h = o;
         }
         TensorRef o; if ((rc = run_rb(m, h, &skip, &o))) return rc;
@@ -619,11 +698,13 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             *bytes = 4.0 * (2.0 * B * p->cfg.in_channels * g->H * g->W + elems(o.dst));
             break;
         case OP_GN:
-            *name = "midd::gn_partial_kernel+gn_finalize_kernel";
-            *flops = 0; *bytes = 4.0 * (elems(o.s0) + (o.has_s1 ? elems(o.s1) : 0));
+            *name = "midd::gn_from_partial_kernel";
+            *flops = 0; *bytes = 8.0 * B * (o.s0.stat_rows * o.s0.C + (o.has_s1 ? o.s1.stat_rows * o.s1.C : 0));
             break;
+        case OP_CHAN_PART: *name = "midd::chan_partial_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
         case OP_CONV: {
-            snprintf(buf, sizeof(buf), "midd::conv_mfma_f32_kernel<%d, %d, %d, %d, %d, %d, %d>", o.tile.ks, o.tile.stride,
+            snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
+                     p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
                      o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn);
             *name = buf;
             const double cin = o.s0.C + (o.has_s1 ? o.s1.C : 0);
@@ -677,15 +758,17 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                                    g->H, g->W, o.dst.C, s);
                 break;
             case OP_GN: {
-                GnArgs a{};
-                a.src0 = F(o.s0.off); a.C0 = o.s0.C;
-                a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
+                GnFromPartialArgs a{};
+                a.part0 = F(o.s0.stat_off); a.rows0 = o.s0.stat_rows; a.C0 = o.s0.C;
+                a.part1 = o.has_s1 ? F(o.s1.stat_off) : nullptr; a.rows1 = o.has_s1 ? o.s1.stat_rows : 0; a.C1 = o.has_s1 ? o.s1.C : 0;
                 a.B = B; a.HW = o.s0.H * o.s0.W; a.gamma = wd + o.gamma; a.beta = wd + o.beta; a.eps = 1e-5f;
-                a.partial = reinterpret_cast<double*>(ws + o.partial_off); a.nsplit = o.nsplit;
                 a.scale = F(o.scale_off); a.shift = F(o.shift_off);
-                e = gn_stats_launch(a, s);
+                e = gn_from_partial_launch(a, s);
                 break;
             }
+            case OP_CHAN_PART:
+                e = chan_partial_launch(F(o.s0.off), F(o.s0.stat_off), B, o.s0.H * o.s0.W, o.s0.C, o.s0.stat_rows, s);
+                break;
             case OP_CONV: {
                 ConvArgs a{};
                 a.src0 = F(o.s0.off); a.C0 = o.s0.C;
@@ -696,8 +779,9 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 if (o.prologue != PRO_RAW) { a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off); }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
-                a.out = F(o.dst.off);
-                e = conv_launch(a, o.tile, s);
+                a.out = F(o.dst.off); a.out_scale = o.out_scale;
+                if (o.want_stats) { a.stat_partial = F(o.dst.stat_off); a.stat_rows = o.dst.stat_rows; }
+                e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
                 break;
             }
             case OP_ATTN:

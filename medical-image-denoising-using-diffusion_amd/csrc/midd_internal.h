@@ -27,6 +27,11 @@ struct ConvArgs {
     const int* trow;        // [B] table row per sample
     const float* resid;     // NHWC [B][OH][OW][Cout] added in the epilogue, or null
     float* out;             // NHWC [B][OH][OW][Cout]
+    float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
+    // optional fused GroupNorm statistics of the OUTPUT: per (sample, row, channel) partial sum and
+    // sum of squares, layout [B][stat_rows][2][Cout]; row = tile*WM + wave_m (see conv_stat_rows)
+    float* stat_partial;
+    int stat_rows;
     int tiles_x, tiles_y;
 };
 
@@ -34,9 +39,22 @@ struct ConvTile {           // which template instance to launch
     int ks, stride, tw, mt, nt, wm, wn;
 };
 
+enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
+
 // Picks a tile for (Cout, output pixels, kernel size, stride); returns false if unsupported.
 bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
 hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
+// rows of the fused-statistics buffer one launch with this tile writes per image
+int conv_stat_rows(const ConvTile& t, int OH, int OW);
+
+// split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
+bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
+hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
+// number of 32-wide K steps the f16x3 kernel walks for (Cin, taps) — shared with the host packer
+__host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
+    const int nblk = Cin / 16, full = nblk / 2, half = nblk & 1;
+    return full * taps + half * ((taps + 1) / 2);
+}
 
 // ---------------------------------------------------------------- GroupNorm statistics
 struct GnArgs {
@@ -50,6 +68,20 @@ struct GnArgs {
 };
 hipError_t gn_stats_launch(const GnArgs& a, hipStream_t s);
 int gn_pick_nsplit(int B, int HW, int C);
+
+// GroupNorm from per-channel partial sums (produced by conv epilogues or chan_partial_launch):
+// up to two sources (torch.cat), each [B][rows][2][C].
+struct GnFromPartialArgs {
+    const float* part0; int rows0, C0;
+    const float* part1; int rows1, C1;
+    int B; int HW;                              // pixels per sample the sums cover
+    const float* gamma; const float* beta; float eps;
+    float* scale; float* shift;                // [B][C0+C1]
+};
+hipError_t gn_from_partial_launch(const GnFromPartialArgs& a, hipStream_t s);
+// per-channel partial sums of an NHWC tensor -> [B][rows][2][C]
+hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int C, int rows, hipStream_t s);
+int chan_partial_rows(int HW, int C);
 
 // ---------------------------------------------------------------- attention
 // qkv: NHWC [B][N][3C], channel = s*C + head*D + d (s in q,k,v);  out: [B][N][C]

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import threading
 from typing import Dict, Optional, Tuple
 
@@ -56,8 +57,12 @@ def _default_init(name: str, shape: Tuple[int, ...], all_shapes: Dict[str, Tuple
 
 class UNetDiffusion(nn.Module):
     def __init__(self, in_channels=1, model_channels=48, channel_mult=(1, 2, 3, 4), num_res_blocks=2,
-                 attention_resolutions=(3,), dropout=0.0, time_emb_dim=192, variant="ddim"):
+                 attention_resolutions=(3,), dropout=0.0, time_emb_dim=192, variant="ddim", compute=None):
         super().__init__()
+        # arithmetic of the MFMA contractions: "f16x3" (split-fp16, default) or "f32" (fp32-input MFMA)
+        self.compute = compute or os.environ.get("MIDD_COMPUTE", "f16x3")
+        if self.compute not in native.MI_COMPUTE:
+            raise ValueError(f"compute must be one of {sorted(native.MI_COMPUTE)}")
         self.cfg = UNetConfig(in_channels, model_channels, tuple(channel_mult), num_res_blocks,
                               tuple(attention_resolutions), dropout, time_emb_dim, variant)
         self.topology = topology(self.cfg)
@@ -108,6 +113,7 @@ class UNetDiffusion(nn.Module):
             for i, a in enumerate(c.attention_resolutions):
                 cfg.attention_levels[i] = a
             cfg.time_emb_dim, cfg.variant = c.time_emb_dim, native.MI_VARIANT[c.variant]
+            cfg.compute_mode = native.MI_COMPUTE[self.compute]
             handle = C.c_void_p()
             native.check(lib.mi_unet_plan_create(C.byref(cfg), C.byref(handle)))
             self._plan = handle.value

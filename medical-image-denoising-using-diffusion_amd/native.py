@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmidd.so")
 MI_MAX_LEVELS = 8
 MI_VARIANT = {"ddim": 0, "cddpm": 1}
 MI_CLAMP_EPS = 1
+MI_COMPUTE = {"f32": 0, "f16x3": 1}
 
 
 class NativeLibraryError(RuntimeError):
@@ -31,7 +32,7 @@ class UNetCfg(C.Structure):
     _fields_ = [("in_channels", C.c_int32), ("model_channels", C.c_int32), ("num_levels", C.c_int32),
                 ("channel_mult", C.c_int32 * MI_MAX_LEVELS), ("num_res_blocks", C.c_int32),
                 ("num_attention_levels", C.c_int32), ("attention_levels", C.c_int32 * MI_MAX_LEVELS),
-                ("time_emb_dim", C.c_int32), ("variant", C.c_int32)]
+                ("time_emb_dim", C.c_int32), ("variant", C.c_int32), ("compute_mode", C.c_int32)]
 
 
 class ProfileEntry(C.Structure):
