@@ -2,27 +2,33 @@
 // v_mfma_f32_16x16x32_f16 products per K-step ("f16x3"), fp32 accumulation, for gfx950.
 //
 // Why: the fp32-input MFMA runs at 1/16 of the fp16 rate (MI355X_MICROARCH.md); fp16 x fp16
-// products are exact in the fp32 accumulator, so with
+// products are exact in the fp32 accumulator, so with the exact power-of-two prescales
 //     x' = x * 2^s :  x' = xh + xl,   xh = fp16(x'),  xl = fp16(x' - xh)       (|err| <= 2^-22 |x'|)
 //     w' = w * 2^k :  w' = wh + wl    (k per layer so that max|w'| ~ 2^14)
 //     w'.x' ~= wh.xh + wh.xl + wl.xh                                          (wl.xl ~ 2^-22 dropped)
 // three fp16 MFMAs into ONE fp32 accumulator reproduce the fp32 product to ~2^-21 relative —
 // the same order as the fp32 accumulation error itself and far inside the 1e-3 parity gate —
-// at 3/16 of the cost.  The power-of-two prescales (exact) keep the low halves in fp16's normal
-// range; the epilogue multiplies by 2^-(k+s) (ConvArgs::out_scale), again exact.
+// at 3/16 of the cost.  The epilogue multiplies by 2^-(k+s) (ConvArgs::out_scale), exactly.
 //
-// Same contract, fusion and launch geometry as conv_mfma_f32.hip (see that file's header):
-// A = packed weights (rows = cout), B = input pixels staged through LDS with GroupNorm-apply
-// (+SiLU) and the fp16 split done once per element while staging; epilogue bias / time
-// embedding / residual, plus optional per-channel partial sums of the OUTPUT for the next
-// GroupNorm (replaces a separate statistics pass over the tensor).
+// Same contract and fusion as conv_mfma_f32.hip (A = packed weights, rows = cout; B = input
+// pixels; GroupNorm-apply(+SiLU) prologue, virtual torch.cat, bias / time-embedding / residual
+// epilogue) plus per-channel partial sums of the OUTPUT for the next GroupNorm.
 //
+// Data movement (what the fp16 rate makes necessary):
+//   * every global->LDS transfer in the K loop is LDS-DMA (global_load_lds_dwordx4): no VGPRs
+//     in flight, exact per-wave instruction counts, so counted s_waitcnt vmcnt(N) + raw
+//     s_barrier keep two weight steps and the next activation chunk in flight across barriers;
+//   * WEIGHTS go through a 3-slot LDS ring shared by all waves of the workgroup (one L2 read
+//     per workgroup and step instead of one per wave: the per-wave register path was L2-bound);
+//   * ACTIVATIONS of the next 32-channel chunk land raw (fp32) in LDS; each thread transforms
+//     the slots it fetched itself (norm, SiLU, 2^s prescale, hi/lo split) into the MFMA image
+//     [block 0/1][hi|lo][halo pixel][16 fp16] (32 B per pixel and plane: a fragment read is
+//     2 x 512 contiguous bytes, conflict-free).
 // K walk: 32 input channels (two 16-channel blocks) per step and tap; a trailing single block
-// (Cin = 48, 144) pairs two TAPS per step instead, so only ceil(9/2)*... one half-step is padded.
-// LDS image per chunk: [block 0/1][hi|lo][halo pixel][16 fp16] (32 B per pixel and plane), so
-// a wave's fragment read is 2 x 512 contiguous bytes, conflict-free.
+// (Cin = 48, 144) pairs two TAPS per step instead.
 #include "midd_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace midd {
 
@@ -57,29 +63,68 @@ __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
     }
 }
 
+// Wait until at most N of this wave's vector-memory operations (all of them LDS-DMA inside the
+// K loop) are outstanding and all its LDS accesses are done, then the workgroup barrier.
+template <int N>
+__device__ __forceinline__ void wait_vm_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
+struct Conv16Geom {
+    static constexpr int NW = WM * WN;
+    static constexpr int NTHREADS = NW * 64;
+    static constexpr int BM = WM * MT * 16;
+    static constexpr int TH = BM / TW;
+    static constexpr int IH = (TH - 1) * STRIDE + KS;
+    static constexpr int IW = (TW - 1) * STRIDE + KS;
+    static constexpr int NPIX = IH * IW;
+    static constexpr int NSLOT = NPIX * 8;                          // 16-byte slots of a 32-channel chunk
+    static constexpr int APW = (NSLOT + NTHREADS - 1) / NTHREADS;   // activation DMA pieces per wave and chunk
+    static constexpr int RAW_BYTES = APW * NTHREADS * 16;
+    static constexpr int PLANE = NPIX * 32;
+    static constexpr int IMG_BYTES = 4 * PLANE;
+    static constexpr int WPIECES = WN * NT * 2;                     // 1 KiB weight pieces per step
+    static constexpr int PPW = (WPIECES + NW - 1) / NW;             // pieces per wave and step (duplicates pad)
+    static constexpr int WSLICE = WPIECES * 1024;
+    static constexpr int MAX_CIN = 512;
+    static constexpr int FIXED_BYTES = RAW_BYTES + IMG_BYTES + 2 * MAX_CIN * 4;
+    // weight steps resident in LDS (prefetch distance RING-1): L2->LDS latency is ~1-2k cycles under
+    // load, a step is only 150-600 MFMA cycles, so take as many slots as fit in half the LDS (two
+    // workgroups per CU), between 2 and 6.
+    static constexpr int ring_fit = (80 * 1024 - FIXED_BYTES) / WSLICE;
+    static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > 6 ? 6 : ring_fit);
+    static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
+    static_assert(BM % TW == 0, "tile");
+};
+
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
-    constexpr int NTHREADS = WM * WN * 64;
-    constexpr int BM = WM * MT * 16;
-    constexpr int TH = BM / TW;
+    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
+    constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
     constexpr int PAD = (KS == 3) ? 1 : 0;
-    constexpr int IH = (TH - 1) * STRIDE + KS;
-    constexpr int IW = (TW - 1) * STRIDE + KS;
-    constexpr int NPIX = IH * IW;
-    constexpr int NSLOT = NPIX * 8;                       // float4 (4-channel) slots per 32-channel chunk
-    constexpr int SPT = (NSLOT + NTHREADS - 1) / NTHREADS;
+    constexpr int NSLOT = G::NSLOT, APW = G::APW, PLANE = G::PLANE;
     constexpr int TAPS = KS * KS;
-    constexpr int HSTEPS = (TAPS + 1) / 2;                // steps of a trailing single-block chunk
-    constexpr int PLANE = NPIX * 32;                      // bytes of one (block, hi|lo) plane
-    constexpr int BUF = 4 * PLANE;
-    static_assert(BM % TW == 0, "tile");
+    constexpr int HSTEPS = (TAPS + 1) / 2;
+    constexpr int PPW = G::PPW, WSLICE = G::WSLICE, RING = G::RING;
 
-    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) char lds[G::LDS_BYTES];
+    char* const raw = lds;
+    char* const img = lds + G::RAW_BYTES;
+    char* const wring = img + G::IMG_BYTES;
+    float* const gnp = reinterpret_cast<float*>(wring + RING * WSLICE);     // [2][MAX_CIN] scale, shift
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WN;
     const int wm = wave / WN;
     const int p16 = lane & 15;
@@ -97,64 +142,95 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int nblk = Cin >> 4;
     const int nchunks = (nblk + 1) >> 1;
     const int ntiles_total = a.Cout >> 4;
-    const int ntile0 = blockIdx.y * (WN * NT) + wn * NT;
+    const int ntile_wg = blockIdx.y * (WN * NT);          // first cout tile of this workgroup
+    const int total_steps = conv16_num_steps(Cin, TAPS);
 
-    // ---- staging geometry: thread -> (halo pixel, 4-channel quad q8 of the 32-channel chunk) ----
-    const int q8 = tid & 7;
-    const int sblk = q8 >> 2;                             // block within the chunk this thread stages
-    int g_off[SPT];
+    // ---- weights: LDS-DMA ring ---------------------------------------------------------------
+    // global layout [step][cout tile][hi|lo][lane] x 16 B; the workgroup's slice of one step is
+    // contiguous.  Everything but the lane offset is wave-uniform, so the address arithmetic stays
+    // on the scalar unit.
+    const char* const wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048;
+    const size_t wstep_bytes = (size_t)ntiles_total * 2048;
+    const int lane16 = lane * 16;
+    int wr_step = 0, wr_slot = 0;                         // next step to fetch / the ring slot it goes to
+    auto issue_w = [&]() {                                // (re-fetches step 0 past the end: never read)
+        if (a.debug & 1) return;
+        char* slot = wring + wr_slot * WSLICE;
+        const char* src = wbase + (size_t)(wr_step < total_steps ? wr_step : 0) * wstep_bytes;
 #pragma unroll
-    for (int s = 0; s < SPT; ++s) {
+        for (int i = 0; i < PPW; ++i) {
+            // WM == 1: every wave owns a distinct cout slice, so it fetches exactly the pieces it
+            // reads itself (no cross-wave hand-off, no barrier per step); otherwise round-robin.
+            int piece = (WM == 1) ? wave * PPW + i : wave + i * NW;
+            if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place
+            dma16(src + piece * 1024 + lane16, slot + piece * 1024);
+        }
+        ++wr_step;
+        wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
+    };
+
+    // ---- activations: per-thread slots (halo pixel, 4-channel quad q8 of the 32-channel chunk) ----
+    const int q8 = tid & 7;
+    const int sblk = q8 >> 2;
+    int g_off[APW];            // pixel index into the image; -1: out of the image; -2: slot beyond the tile
+#pragma unroll
+    for (int s = 0; s < APW; ++s) {
         const int slot = tid + s * NTHREADS;
-        int off = -1;
+        int off = -2;
         if (slot < NSLOT) {
             const int pix = slot >> 3;
             const int iy = pix / IW, ix = pix - iy * IW;
             const int gy = iy0 + iy, gx = ix0 + ix;
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) off = (b * a.H + gy) * a.W + gx;
+            off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (b * a.H + gy) * a.W + gx : -1;
         }
         g_off[s] = off;
     }
-
-    f32x4 stage[SPT];
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    bool stage_active = false;
-
-    auto stage_load = [&](int c) {
-        const int blk = 2 * c + sblk;
-        stage_active = blk < nblk;
-        if (!stage_active) return;
+    // Lanes with nothing to fetch (padding, unused slots, missing second block) read a valid
+    // dummy address; transform() writes zeros / nothing for them.
+    auto issue_a = [&](int c) {
+        if (a.debug & 2) return;
+        const int blk = min(2 * c + sblk, nblk - 1);
         const int ch = (blk << 4) + (q8 & 3) * 4;
-        const float* src; int Cs, coff;
-        if (ch < a.C0) { src = a.src0; Cs = a.C0; coff = ch; }
-        else           { src = a.src1; Cs = a.C1; coff = ch - a.C0; }
+        const float* src; unsigned cs4, coff;
+        if (ch < a.C0) { src = a.src0; cs4 = a.C0 * 4u; coff = ch * 4u; }
+        else           { src = a.src1; cs4 = a.C1 * 4u; coff = (ch - a.C0) * 4u; }
+        const char* base = reinterpret_cast<const char*>(src);
 #pragma unroll
-        for (int s = 0; s < SPT; ++s) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g_off[s] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)g_off[s] * Cs + coff);
-            stage[s] = v;
-        }
-        if (a.prologue != PRO_RAW) {
-            sc = *reinterpret_cast<const f32x4*>(a.gn_scale + (size_t)b * Cin + ch);
-            sh = *reinterpret_cast<const f32x4*>(a.gn_shift + (size_t)b * Cin + ch);
+        for (int s = 0; s < APW; ++s) {
+            const unsigned byte_off = (unsigned)max(g_off[s], 0) * cs4 + coff;      // tensors are < 4 GiB (host-checked)
+            dma16(base + byte_off, raw + (wave + s * NW) * 1024);
         }
     };
-    auto stage_store = [&](int buf) {
-        if (!stage_active) return;
-        char* base = lds + buf * BUF + sblk * 2 * PLANE + (q8 & 3) * 8;
+    auto transform = [&](int c) {
+        const int blk = 2 * c + sblk;
+        if (blk >= nblk || (a.debug & 16)) return;
+        const int ch = (blk << 4) + (q8 & 3) * 4;
+        // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
+        f32x4 sc = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (a.prologue != PRO_RAW) {
+            sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
+            sh = *reinterpret_cast<const f32x4*>(gnp + G::MAX_CIN + ch) * ACT_PRESCALE;
+        }
+        char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
 #pragma unroll
-        for (int s = 0; s < SPT; ++s) {
+        for (int s = 0; s < APW; ++s) {
             const int slot = tid + s * NTHREADS;
-            if (slot < NSLOT) {
-                f32x4 v = stage[s];
-                if (a.prologue != PRO_RAW && g_off[s] >= 0) {
-                    v = v * sc + sh;
-                    if (a.prologue == PRO_GN_SILU) {
-                        v.x = silu16(v.x); v.y = silu16(v.y); v.z = silu16(v.z); v.w = silu16(v.w);
-                    }
-                }   // out-of-image pixels stay exactly zero: the conv pads its (normalised) input
+            if (g_off[s] > -2) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(raw + slot * 16);
+                v = v * sc + sh;
+                if (a.prologue == PRO_GN_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
+                        v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+                }
+                if (g_off[s] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // the conv pads its (normalised) input with zeros
                 half4 hi, lo;
-                split4(v, hi, lo);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)v[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)(v[e] - (float)h);
+                }
                 const int pix = slot >> 3;
                 *reinterpret_cast<half4*>(base + pix * 32) = hi;
                 *reinterpret_cast<half4*>(base + PLANE + pix * 32) = lo;
@@ -170,7 +246,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         const int py = pp / TW, px = pp - py * TW;
         frag_base[mt] = ((py * STRIDE) * IW + px * STRIDE) * 32 + (kq & 1) * 16;
     }
-    const int kblk_off = (kq >> 1) * 2 * PLANE;           // full chunk: lanes kq>=2 read block 1
+    int frag_full[MT];                                    // full chunk: lanes kq>=2 read block 1
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) frag_full[mt] = frag_base[mt] + (kq >> 1) * 2 * PLANE;
+    const int wfrag_off = (wn * NT) * 2048 + lane * 16;   // this wave's cout tiles inside a ring slot
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -178,36 +257,49 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // weights: [step][cout tile][hi|lo][lane] x 16 B
-    const half8* wp = reinterpret_cast<const half8*>(a.wpack) + (size_t)ntile0 * 128 + lane;
-    const size_t wstep = (size_t)ntiles_total * 128;
-    // weight fragments are fetched two steps ahead (L2 latency > one step of MFMAs)
-    half8 wh[NT], wl[NT], w1h[NT], w1l[NT], w2h[NT], w2l[NT];
-    const int total_steps = conv16_num_steps(Cin, TAPS);
+    // ---- K loop -------------------------------------------------------------------------------
+    // DMA protocol (D = RING-1 weight steps in flight).  Per wave, in program order:
+    //   prologue : A(0) W(0)..W(D-1)                                   -> wait 0
+    //   step s   : wait; barrier; issue W(s+D) [; issue A(c+1) in the first step of a chunk]; MFMAs
+    //   chunk end: wait; barrier; transform(c+1)
+    // When step s waits, the groups younger than W(s) are W(s+1..s+D-1), plus A(c+1) during steps
+    // 1..D of the chunk (afterwards A(c+1) is older than W(s), i.e. already forced complete):
+    //   N = (D-1)*PPW [+ APW].   At the chunk end the groups younger than A(c+1) are the
+    // min(nsteps-1, D) weight groups issued after it.  The slot refilled after the barrier of step
+    // s, (s+D)%RING == (s-1)%RING, was last read before that barrier by every wave.
+    constexpr int D = RING - 1;
+    issue_a(0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        wh[nt] = wp[nt * 128]; wl[nt] = wp[nt * 128 + 64];
-        const half8* w1 = wp + (size_t)(total_steps > 1 ? 1 : 0) * wstep;
-        w1h[nt] = w1[nt * 128]; w1l[nt] = w1[nt * 128 + 64];
-    }
-    int step = 0;
-
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-
-    auto do_step = [&](const char* buf, const int (&xo)[MT]) {
-        {
-            const int ns = (step + 2 < total_steps) ? step + 2 : 0;   // wraps harmlessly at the end
-            const half8* w2 = wp + (size_t)ns * wstep;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { w2h[nt] = w2[nt * 128]; w2l[nt] = w2[nt * 128 + 64]; }
+    for (int i = 0; i < D; ++i) issue_w();
+    if (a.prologue != PRO_RAW) {
+        for (int i = tid; i < Cin; i += NTHREADS) {
+            gnp[i] = a.gn_scale[(size_t)b * Cin + i];
+            gnp[G::MAX_CIN + i] = a.gn_shift[(size_t)b * Cin + i];
         }
-        half8 xh[MT], xl[MT];
+    }
+    wait_vm_and_barrier<0>();               // everything above has landed / is visible (once per launch)
+    transform(0);
+    if constexpr (WM == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    int rd_slot = 0;
+    auto mfma_step = [&](const int (&xo)[MT]) {
+        const char* wslot = wring + rd_slot * WSLICE + wfrag_off;
+        rd_slot = (rd_slot + 1 == RING) ? 0 : rd_slot + 1;
+        if (a.debug & 4) return;
+        half8 wh[NT], wl[NT], xh[MT], xl[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
+            wl[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            xh[mt] = *reinterpret_cast<const half8*>(buf + xo[mt]);
-            xl[mt] = *reinterpret_cast<const half8*>(buf + xo[mt] + PLANE);
+            xh[mt] = *reinterpret_cast<const half8*>(img + xo[mt]);
+            xl[mt] = *reinterpret_cast<const half8*>(img + xo[mt] + PLANE);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -224,45 +316,73 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { wh[nt] = w1h[nt]; wl[nt] = w1l[nt]; w1h[nt] = w2h[nt]; w1l[nt] = w2l[nt]; }
-        ++step;
     };
 
-    int cur = 0;
+    auto k_step = [&](auto with_a, bool first_with_more, int c, const int (&xo)[MT]) {
+        constexpr bool WITH_A = decltype(with_a)::value;
+        constexpr int N = (D - 1) * PPW + (WITH_A ? APW : 0);
+        if constexpr (WM == 1) {
+            // own weights only: the counted wait orders this wave's LDS reads behind its own DMA
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        } else {
+            wait_vm_and_barrier<N>();
+        }
+        issue_w();
+        if (first_with_more) issue_a(c + 1);       // each thread already consumed its own raw slots of chunk c
+        mfma_step(xo);
+    };
+
     for (int c = 0; c < nchunks; ++c) {
         const bool more = (c + 1 < nchunks);
-        if (more) stage_load(c + 1);
-        const char* buf = lds + cur * BUF;
-        if (2 * c + 1 < nblk) {
-            // full chunk: one tap and 32 channels per step; lane group kq>>1 selects the block
+        const bool full = (2 * c + 1 < nblk);
+        auto run_chunk = [&](auto more_t) {
+            constexpr bool MORE = decltype(more_t)::value;
+            if (full) {
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
-                const int dy = tap / KS, dx = tap - dy * KS;
-                int xo[MT];
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int dy = tap / KS, dx = tap - dy * KS;
+                    int xo[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + kblk_off + (dy * IW + dx) * 32;
-                do_step(buf, xo);
+                    for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_full[mt] + (dy * IW + dx) * 32;
+                    if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, c, xo);
+                    else                              k_step(std::false_type{}, MORE && tap == 0, c, xo);
+                }
+            } else {
+#pragma unroll
+                for (int hs = 0; hs < HSTEPS; ++hs) {
+                    const int t0 = 2 * hs, t1 = (2 * hs + 1 < TAPS) ? 2 * hs + 1 : 0;   // padded half has zero weights
+                    const int o0 = ((t0 / KS) * IW + (t0 % KS)) * 32, o1 = ((t1 / KS) * IW + (t1 % KS)) * 32;
+                    const int to = (kq >> 1) ? o1 : o0;
+                    int xo[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
+                    if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, c, xo);
+                    else                            k_step(std::false_type{}, MORE && hs == 0, c, xo);
+                }
+            }
+        };
+        if (more) {
+            run_chunk(std::true_type{});
+            // every wave is done reading the image, and A(c+1) (older than the last min(nsteps-1, D)
+            // weight groups) has landed, before the image is rewritten
+            const int nsteps = full ? TAPS : HSTEPS;
+            if (nsteps - 1 >= D) wait_vm_and_barrier<D * PPW>();
+            else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
+            else wait_vm_and_barrier<0>();
+            transform(c + 1);
+            if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
         } else {
-            // trailing single block: two taps per step; lane group kq>>1 selects the tap
-#pragma unroll
-            for (int hs = 0; hs < HSTEPS; ++hs) {
-                const int t0 = 2 * hs, t1 = (2 * hs + 1 < TAPS) ? 2 * hs + 1 : 0;   // padded half has zero weights
-                const int o0 = ((t0 / KS) * IW + (t0 % KS)) * 32, o1 = ((t1 / KS) * IW + (t1 % KS)) * 32;
-                const int to = (kq >> 1) ? o1 : o0;
-                int xo[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
-                do_step(buf, xo);
-            }
+            run_chunk(std::false_type{});
         }
-        if (more) stage_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the padding refills past the last step
 
     // ---- epilogue ---------------------------------------------------------------------------
+    const int ntile0 = ntile_wg + wn * NT;
     const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
     f32x4 ssum[NT], ssq[NT];
 #pragma unroll
@@ -288,7 +408,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         }
     }
     if (a.stat_partial != nullptr) {
-        // fold the 16 pixel lanes (fixed xor tree -> deterministic), lanes p16 == 0 publish 4 channels each
+        // fold the 16 pixel lanes (fixed order -> deterministic), lanes p16 == 0 publish 4 channels each
         const int row = trem * WM + wm;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -307,15 +427,17 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------ dispatch
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
+    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     ConvArgs a = a0;
-    constexpr int BM = WM * MT * 16;
-    constexpr int TH = BM / TW;
+    static const int dbg = getenv("MIDD_DEBUG") ? atoi(getenv("MIDD_DEBUG")) : 0;
+    a.debug = dbg;
     a.tiles_x = (a.OW + TW - 1) / TW;
-    a.tiles_y = (a.OH + TH - 1) / TH;
+    a.tiles_y = (a.OH + G::TH - 1) / G::TH;
     dim3 grid(a.B * a.tiles_x * a.tiles_y, a.Cout / (WN * NT * 16));
-    constexpr int IH = (TH - 1) * STRIDE + KS, IW = (TW - 1) * STRIDE + KS;
-    if constexpr (2 * 4 * IH * IW * 32 <= 160 * 1024) {
-        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(WM * WN * 64), 0, s, a);
+    if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
+        if (a.C0 + a.C1 > G::MAX_CIN) return hipErrorInvalidValue;
+        if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets
+        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(G::NTHREADS), 0, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;        // tile never picked (conv16_pick_tile), not instantiated
@@ -344,6 +466,20 @@ static const Tile16 kTiles16[] = {
 #undef X
 };
 
+// run-time mirror of Conv16Geom::LDS_BYTES / the vmcnt-encoding limit, for the tile picker
+static bool tile16_fits(const Tile16& d, int ks, int stride) {
+    const int nw = d.wm * d.wn, nthreads = nw * 64;
+    const int bm = d.wm * d.mt * 16, th = bm / d.tw;
+    const int ih = (th - 1) * stride + ks, iw = (d.tw - 1) * stride + ks;
+    const int npix = ih * iw, apw = (npix * 8 + nthreads - 1) / nthreads;
+    const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
+    const long fixed = (long)apw * nthreads * 16 + 4L * npix * 32 + 2 * 512 * 4;
+    long ring = (80 * 1024 - fixed) / (wpieces * 1024);
+    ring = ring < 2 ? 2 : (ring > 6 ? 6 : ring);
+    const long lds = fixed + ring * wpieces * 1024;
+    return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
+}
+
 bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t) {
     if (Cout % 16) return false;
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
@@ -354,17 +490,18 @@ bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvT
         if (nn % cand == 0) { wn = cand; break; }
     const Tile16* best = nullptr;
     long best_score = -(1L << 60);
-    static const int max_mt = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 4;   // tuning knob
+    static const int max_mt = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 2;   // tuning knobs (measured: 2 beats 4)
+    static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 512;
     for (const Tile16& d : kTiles16) {
         if (d.nt != nt || d.wn != wn) continue;
         if (d.mt > max_mt) continue;
-        if (stride == 2 && d.mt > 2) continue;                 // 33x33 halo of a 16x16 s2 tile does not pay
+        if (!tile16_fits(d, ks, stride)) continue;
         const int bm = d.wm * d.mt * 16, th = bm / d.tw;
         const long tiles = (long)((OW + d.tw - 1) / d.tw) * ((OH + th - 1) / th);
         const long wgs = (long)B * tiles * (Cout / (wn * nt * 16));
         const long covered = tiles * d.tw * th;
         const bool wasteful = covered * 4 > (long)OH * OW * 5;
-        const long score = (wgs >= 512 ? 1000000 : wgs * 1000) + bm - (wasteful ? 500000 : 0);
+        const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + bm - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }
     }
     if (!best) return false;

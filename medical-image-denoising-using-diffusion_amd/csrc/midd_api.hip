@@ -95,7 +95,7 @@ struct mi_plan {
     // device side
     float* wdev = nullptr; size_t wdev_floats = 0;
     float* ttab = nullptr; int time_rows = 0;
-    size_t w_in = 0, b_in = 0, g_out = 0, be_out = 0, w_out = 0, b_out = 0;
+    size_t w_in = 0, b_in = 0, g_out = 0, be_out = 0, w_out = 0, b_out = 0, zeros_off = 0;
     bool finalized = false;
     int device = -1;
     std::mutex mu;
@@ -425,6 +425,7 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
         if (!getw(plan, k)) return fail(MI_ESTATE, "missing key in state_dict: \"%s\"", k.c_str());
 
     Packer pk;
+    { std::vector<float> z(64, 0.f); plan->zeros_off = pk.put(z); }
     const bool f16 = plan->cfg.compute_mode == MI_COMPUTE_F16X3;
     auto pack_conv = [&](const float* w, int Cout, int Cin, int KS, float* scale) {
         *scale = 1.0f;
@@ -779,7 +780,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 if (o.prologue != PRO_RAW) { a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off); }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
-                a.out = F(o.dst.off); a.out_scale = o.out_scale;
+                a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;
                 if (o.want_stats) { a.stat_partial = F(o.dst.stat_off); a.stat_rows = o.dst.stat_rows; }
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
                 break;
