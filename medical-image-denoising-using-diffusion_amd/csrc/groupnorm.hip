@@ -133,7 +133,19 @@ void gn_from_partial_kernel(const GnFromPartialArgs a) {
         if (c < a.C0) { p = a.part0; rows = a.rows0; Cs = a.C0; cl = c; }
         else          { p = a.part1; rows = a.rows1; Cs = a.C1; cl = c - a.C0; }
         p += (size_t)b * rows * 2 * Cs + cl;
-        for (int r = rl; r < rows; r += nrl) {
+        // 8 rows in flight per thread (the loads are L2-latency bound); fixed summation order
+        int r = rl;
+        for (; r + 7 * nrl < rows; r += 8 * nrl) {
+            float v1[8], v2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v1[u] = p[(size_t)(r + u * nrl) * 2 * Cs];
+                v2[u] = p[(size_t)(r + u * nrl) * 2 * Cs + Cs];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+        }
+        for (; r < rows; r += nrl) {
             s1 += (double)p[(size_t)r * 2 * Cs];
             s2 += (double)p[(size_t)r * 2 * Cs + Cs];
         }

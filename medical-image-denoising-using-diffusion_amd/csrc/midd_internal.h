@@ -88,6 +88,9 @@ int chan_partial_rows(int HW, int C);
 // ---------------------------------------------------------------- attention
 // qkv: NHWC [B][N][3C], channel = s*C + head*D + d (s in q,k,v);  out: [B][N][C]
 hipError_t attention_launch(const float* qkv, float* out, int B, int N, int C, int heads, hipStream_t s);
+// split-fp16 variant; `scratch` (attention16_scratch_bytes) holds the pre-split K and V^T images
+hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int N, int C, int heads, hipStream_t s);
+size_t attention16_scratch_bytes(int B, int N, int C);
 bool attention_supported(int head_dim);
 
 // ---------------------------------------------------------------- small direct kernels
@@ -107,8 +110,20 @@ struct OutConvArgs {
     const float* noise;     // NCHW or null
     float c1, c2, c3;
     int clamp_eps;
+    // graph-replay form: when sched != null the coefficients and the noise slice of the current
+    // iteration are read from device memory (entry *step_counter), so one captured forward serves
+    // every iteration of the sampler loop
+    const struct StepSched* sched;
+    const int* step_counter;
+    size_t noise_stride;    // elements between consecutive iterations' noise tensors
 };
 hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s);
+
+// One iteration of the sampler loop as the device sees it (DDIMModel.py:275-283).
+struct StepSched { float c1, c2, c3; int t; int use_noise; int pad[3]; };
+// trow[b] = sched[*counter].t for all b  /  ++*counter   (first and last node of a captured forward)
+hipError_t step_begin_launch(const StepSched* sched, const int* counter, int* trow, int B, hipStream_t s);
+hipError_t step_end_launch(int* counter, hipStream_t s);
 
 // bilinear resize NHWC (align_corners=False), any size ratio
 hipError_t resize_bilinear_launch(const float* src, float* dst, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
