@@ -162,7 +162,7 @@ def main():
             [dict(name=p["name"], launches=p["launches"], ms=round(p["total_ms"], 3),
                   tflops=round(p["flops"] / (p["total_ms"] * 1e-3) / 1e12, 2) if p["flops"] else None,
                   GBps=round(p["bytes"] / (p["total_ms"] * 1e-3) / 1e9, 1)) for p in prof],
-            key=lambda d: -d["ms"])[:8]
+            key=lambda d: -d["ms"])[:24]
 
         # ---- CPU baseline (rank 0, N = 1 only) + a parity spot check on the same sample ----
         if world == 1 and args.cpu_iters > 0 and S <= 512:

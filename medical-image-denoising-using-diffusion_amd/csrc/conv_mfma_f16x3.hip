@@ -86,11 +86,13 @@ struct Conv16Geom {
     static constexpr int IH = (TH - 1) * STRIDE + KS;
     static constexpr int IW = (TW - 1) * STRIDE + KS;
     static constexpr int NPIX = IH * IW;
-    static constexpr int NSLOT = NPIX * 8;                          // 16-byte slots of a 32-channel chunk
+    static constexpr int CB = CONV16_CB;                            // 16-channel blocks per chunk
+    static constexpr int QPP = 4 * CB;                              // 16-byte slots per halo pixel and chunk
+    static constexpr int NSLOT = NPIX * QPP;
     static constexpr int APW = (NSLOT + NTHREADS - 1) / NTHREADS;   // activation DMA pieces per wave and chunk
     static constexpr int RAW_BYTES = APW * NTHREADS * 16;
     static constexpr int PLANE = NPIX * 32;
-    static constexpr int IMG_BYTES = 4 * PLANE;
+    static constexpr int IMG_BYTES = 2 * CB * PLANE;
     static constexpr int WPIECES = WN * NT * 2;                     // 1 KiB weight pieces per step
     static constexpr int PPW = (WPIECES + NW - 1) / NW;             // pieces per wave and step (duplicates pad)
     static constexpr int WSLICE = WPIECES * 1024;
@@ -99,7 +101,8 @@ struct Conv16Geom {
     // weight steps resident in LDS (prefetch distance RING-1): L2->LDS latency is ~1-2k cycles under
     // load, a step is only 150-600 MFMA cycles, so take as many slots as fit in half the LDS (two
     // workgroups per CU), between 2 and 6.
-    static constexpr int ring_fit = (80 * 1024 - FIXED_BYTES) / WSLICE;
+    static constexpr int LDS_TARGET = (CB == 1 ? 52 : 80) * 1024;   // three / two workgroups per CU
+    static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > 6 ? 6 : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
     static_assert(BM % TW == 0, "tile");
@@ -140,7 +143,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 
     const int Cin = a.C0 + a.C1;
     const int nblk = Cin >> 4;
-    const int nchunks = (nblk + 1) >> 1;
+    constexpr int CB = G::CB, QPP = G::QPP;
+    const int nchunks = (nblk + CB - 1) / CB;
     const int ntiles_total = a.Cout >> 4;
     const int ntile_wg = blockIdx.y * (WN * NT);          // first cout tile of this workgroup
     const int total_steps = conv16_num_steps(Cin, TAPS);
@@ -170,7 +174,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     };
 
     // ---- activations: per-thread slots (halo pixel, 4-channel quad q8 of the 32-channel chunk) ----
-    const int q8 = tid & 7;
+    const int q8 = tid % QPP;                             // (NTHREADS % QPP == 0: constant per thread)
     const int sblk = q8 >> 2;
     int g_off[APW];            // pixel index into the image; -1: out of the image; -2: slot beyond the tile
 #pragma unroll
@@ -178,7 +182,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         const int slot = tid + s * NTHREADS;
         int off = -2;
         if (slot < NSLOT) {
-            const int pix = slot >> 3;
+            const int pix = slot / QPP;
             const int iy = pix / IW, ix = pix - iy * IW;
             const int gy = iy0 + iy, gx = ix0 + ix;
             off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (b * a.H + gy) * a.W + gx : -1;
@@ -189,7 +193,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // dummy address; transform() writes zeros / nothing for them.
     auto issue_a = [&](int c) {
         if (a.debug & 2) return;
-        const int blk = min(2 * c + sblk, nblk - 1);
+        const int blk = min(CB * c + sblk, nblk - 1);
         const int ch = (blk << 4) + (q8 & 3) * 4;
         const float* src; unsigned cs4, coff;
         if (ch < a.C0) { src = a.src0; cs4 = a.C0 * 4u; coff = ch * 4u; }
@@ -202,7 +206,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         }
     };
     auto transform = [&](int c) {
-        const int blk = 2 * c + sblk;
+        const int blk = CB * c + sblk;
         if (blk >= nblk || (a.debug & 16)) return;
         const int ch = (blk << 4) + (q8 & 3) * 4;
         // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
@@ -231,7 +235,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     hi[e] = h;
                     lo[e] = (_Float16)(v[e] - (float)h);
                 }
-                const int pix = slot >> 3;
+                const int pix = slot / QPP;
                 *reinterpret_cast<half4*>(base + pix * 32) = hi;
                 *reinterpret_cast<half4*>(base + PLANE + pix * 32) = lo;
             }
@@ -334,7 +338,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 
     for (int c = 0; c < nchunks; ++c) {
         const bool more = (c + 1 < nchunks);
-        const bool full = (2 * c + 1 < nblk);
+        const bool full = (CB == 2) && (2 * c + 1 < nblk);
         auto run_chunk = [&](auto more_t) {
             constexpr bool MORE = decltype(more_t)::value;
             if (full) {
@@ -471,10 +475,10 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int nw = d.wm * d.wn, nthreads = nw * 64;
     const int bm = d.wm * d.mt * 16, th = bm / d.tw;
     const int ih = (th - 1) * stride + ks, iw = (d.tw - 1) * stride + ks;
-    const int npix = ih * iw, apw = (npix * 8 + nthreads - 1) / nthreads;
+    const int npix = ih * iw, apw = (npix * 4 * CONV16_CB + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
-    const long fixed = (long)apw * nthreads * 16 + 4L * npix * 32 + 2 * 512 * 4;
-    long ring = (80 * 1024 - fixed) / (wpieces * 1024);
+    const long fixed = (long)apw * nthreads * 16 + 2L * CONV16_CB * npix * 32 + 2 * 512 * 4;
+    long ring = ((CONV16_CB == 1 ? 52 : 80) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > 6 ? 6 : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
@@ -484,24 +488,25 @@ bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvT
     if (Cout % 16) return false;
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
-    const int nn = Cout / (16 * nt);
-    int wn = 1;
-    for (int cand = 4; cand >= 1; --cand)
-        if (nn % cand == 0) { wn = cand; break; }
+    const int nn = Cout / (16 * nt);                      // cout slices of 16*nt; a workgroup takes wn of them
     const Tile16* best = nullptr;
     long best_score = -(1L << 60);
     static const int max_mt = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 2;   // tuning knobs (measured: 2 beats 4)
-    static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 512;
+    static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 256;
+    static const int pix_first = getenv("MIDD_PIX_FIRST") ? atoi(getenv("MIDD_PIX_FIRST")) : 1;
     for (const Tile16& d : kTiles16) {
-        if (d.nt != nt || d.wn != wn) continue;
+        if (d.nt != nt || nn % d.wn) continue;
         if (d.mt > max_mt) continue;
         if (!tile16_fits(d, ks, stride)) continue;
         const int bm = d.wm * d.mt * 16, th = bm / d.tw;
         const long tiles = (long)((OW + d.tw - 1) / d.tw) * ((OH + th - 1) / th);
-        const long wgs = (long)B * tiles * (Cout / (wn * nt * 16));
+        const long wgs = (long)B * tiles * (nn / d.wn);
         const long covered = tiles * d.tw * th;
         const bool wasteful = covered * 4 > (long)OH * OW * 5;
-        const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + bm - (wasteful ? 500000 : 0);
+        // enough workgroups first; then the pixels one weight fetch is shared over (the weight stream
+        // from L2 is what starves small tiles), then the couts one activation staging is shared over
+        const long share = pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm;
+        const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }
     }
     if (!best) return false;

@@ -345,9 +345,14 @@ static std::vector<float> pack_conv_f16x3(const float* w, int Cout, int Cin, int
             }
         ++step;
     };
-    for (int c = 0; 2 * c < nblk; ++c) {
-        if (2 * c + 1 < nblk) for (int t = 0; t < taps; ++t) emit(2 * c, 2 * c + 1, t, t);
-        else for (int hs = 0; hs < (taps + 1) / 2; ++hs) emit(2 * c, 2 * c, 2 * hs, 2 * hs + 1);
+    if (CONV16_CB == 1) {
+        for (int blk = 0; blk < nblk; ++blk)
+            for (int hs = 0; hs < (taps + 1) / 2; ++hs) emit(blk, blk, 2 * hs, 2 * hs + 1);
+    } else {
+        for (int c = 0; 2 * c < nblk; ++c) {
+            if (2 * c + 1 < nblk) for (int t = 0; t < taps; ++t) emit(2 * c, 2 * c + 1, t, t);
+            else for (int hs = 0; hs < (taps + 1) / 2; ++hs) emit(2 * c, 2 * c, 2 * hs, 2 * hs + 1);
+        }
     }
     std::vector<float> words(out.size() / 2);
     memcpy(words.data(), out.data(), out.size() * sizeof(_Float16));
