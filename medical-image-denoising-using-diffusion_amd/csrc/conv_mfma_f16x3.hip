@@ -133,13 +133,13 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int p16 = lane & 15;
     const int kq = lane >> 4;
 
+    // Persistent workgroups: blockIdx.x = (sample, j); the workgroup walks tiles j, j+wgs_per_img, ...
+    // of ITS sample, so the weight ring streams cyclically across tiles and the next tile's first
+    // activation chunk is already in flight while this tile is finished and stored.
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles_per_img;
-    const int trem = blockIdx.x - b * tiles_per_img;
-    const int ty = trem / a.tiles_x;
-    const int tx = trem - ty * a.tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+    const int b = blockIdx.x / a.wgs_per_img;
+    int trem = blockIdx.x - b * a.wgs_per_img;            // current tile of this sample
+    int oy0 = (trem / a.tiles_x) * TH, ox0 = (trem % a.tiles_x) * TW;
 
     const int Cin = a.C0 + a.C1;
     const int nblk = Cin >> 4;
@@ -157,10 +157,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const size_t wstep_bytes = (size_t)ntiles_total * 2048;
     const int lane16 = lane * 16;
     int wr_step = 0, wr_slot = 0;                         // next step to fetch / the ring slot it goes to
-    auto issue_w = [&]() {                                // (re-fetches step 0 past the end: never read)
+    auto issue_w = [&]() {
         if (a.debug & 1) return;
         char* slot = wring + wr_slot * WSLICE;
-        const char* src = wbase + (size_t)(wr_step < total_steps ? wr_step : 0) * wstep_bytes;
+        const char* src = wbase + (size_t)wr_step * wstep_bytes;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             // WM == 1: every wave owns a distinct cout slice, so it fetches exactly the pieces it
@@ -169,7 +169,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place
             dma16(src + piece * 1024 + lane16, slot + piece * 1024);
         }
-        ++wr_step;
+        wr_step = (wr_step + 1 == total_steps) ? 0 : wr_step + 1;   // cyclic: step 0 of the next tile follows the last
         wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
     };
 
@@ -177,18 +177,22 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int q8 = tid % QPP;                             // (NTHREADS % QPP == 0: constant per thread)
     const int sblk = q8 >> 2;
     int g_off[APW];            // pixel index into the image; -1: out of the image; -2: slot beyond the tile
+    auto set_tile = [&](int t) {
+        const int iy0 = (t / a.tiles_x) * TH * STRIDE - PAD, ix0 = (t % a.tiles_x) * TW * STRIDE - PAD;
 #pragma unroll
-    for (int s = 0; s < APW; ++s) {
-        const int slot = tid + s * NTHREADS;
-        int off = -2;
-        if (slot < NSLOT) {
-            const int pix = slot / QPP;
-            const int iy = pix / IW, ix = pix - iy * IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (b * a.H + gy) * a.W + gx : -1;
+        for (int s = 0; s < APW; ++s) {
+            const int slot = tid + s * NTHREADS;
+            int off = -2;
+            if (slot < NSLOT) {
+                const int pix = slot / QPP;
+                const int iy = pix / IW, ix = pix - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (b * a.H + gy) * a.W + gx : -1;
+            }
+            g_off[s] = off;
         }
-        g_off[s] = off;
-    }
+    };
+    set_tile(trem);
     // Lanes with nothing to fetch (padding, unused slots, missing second block) read a valid
     // dummy address; transform() writes zeros / nothing for them.
     auto issue_a = [&](int c) {
@@ -322,7 +326,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
     };
 
-    auto k_step = [&](auto with_a, bool first_with_more, int c, const int (&xo)[MT]) {
+    auto k_step = [&](auto with_a, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
         constexpr bool WITH_A = decltype(with_a)::value;
         constexpr int N = (D - 1) * PPW + (WITH_A ? APW : 0);
         if constexpr (WM == 1) {
@@ -332,100 +336,127 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             wait_vm_and_barrier<N>();
         }
         issue_w();
-        if (first_with_more) issue_a(c + 1);       // each thread already consumed its own raw slots of chunk c
+        if (first_with_more) issue_a(next_chunk);  // each thread already consumed its own raw slots
         mfma_step(xo);
     };
 
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1 < nchunks);
-        const bool full = (CB == 2) && (2 * c + 1 < nblk);
-        auto run_chunk = [&](auto more_t) {
-            constexpr bool MORE = decltype(more_t)::value;
-            if (full) {
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    const int dy = tap / KS, dx = tap - dy * KS;
-                    int xo[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_full[mt] + (dy * IW + dx) * 32;
-                    if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, c, xo);
-                    else                              k_step(std::false_type{}, MORE && tap == 0, c, xo);
-                }
-            } else {
-#pragma unroll
-                for (int hs = 0; hs < HSTEPS; ++hs) {
-                    const int t0 = 2 * hs, t1 = (2 * hs + 1 < TAPS) ? 2 * hs + 1 : 0;   // padded half has zero weights
-                    const int o0 = ((t0 / KS) * IW + (t0 % KS)) * 32, o1 = ((t1 / KS) * IW + (t1 % KS)) * 32;
-                    const int to = (kq >> 1) ? o1 : o0;
-                    int xo[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
-                    if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, c, xo);
-                    else                            k_step(std::false_type{}, MORE && hs == 0, c, xo);
-                }
-            }
-        };
-        if (more) {
-            run_chunk(std::true_type{});
-            // every wave is done reading the image, and A(c+1) (older than the last min(nsteps-1, D)
-            // weight groups) has landed, before the image is rewritten
-            const int nsteps = full ? TAPS : HSTEPS;
-            if (nsteps - 1 >= D) wait_vm_and_barrier<D * PPW>();
-            else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
-            else wait_vm_and_barrier<0>();
-            transform(c + 1);
-            if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-        } else {
-            run_chunk(std::false_type{});
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the padding refills past the last step
-
-    // ---- epilogue ---------------------------------------------------------------------------
+    // ---- epilogue (per tile) ------------------------------------------------------------------
     const int ntile0 = ntile_wg + wn * NT;
-    const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
-    f32x4 ssum[NT], ssq[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int co = (ntile0 + nt) * 16 + kq * 4;
-        f32x4 add = *reinterpret_cast<const f32x4*>(a.bias + co);
-        if (a.temb != nullptr)
-            add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)trow * a.temb_stride + co);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int pp = (wm * MT + mt) * 16 + p16;
-            const int py = pp / TW, px = pp - py * TW;
-            const int oy = oy0 + py, ox = ox0 + px;
-            if (oy < a.OH && ox < a.OW) {
-                const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
-                f32x4 v = acc[mt][nt] * a.out_scale + add;
-                if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-                *reinterpret_cast<f32x4*>(a.out + o) = v;
-                ssum[nt] += v; ssq[nt] += v * v;
-            }
-        }
-    }
-    if (a.stat_partial != nullptr) {
-        // fold the 16 pixel lanes (fixed order -> deterministic), lanes p16 == 0 publish 4 channels each
-        const int row = trem * WM + wm;
+    f32x4 add_v[NT];                                      // bias (+ time embedding), loaded once per workgroup
+    {
+        const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
-            if (p16 == 0) {
-                const int co = (ntile0 + nt) * 16 + kq * 4;
-                float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
-                *reinterpret_cast<f32x4*>(pr) = ssum[nt];
-                *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
-            }
+            const int co = (ntile0 + nt) * 16 + kq * 4;
+            add_v[nt] = *reinterpret_cast<const f32x4*>(a.bias + co);
+            if (a.temb != nullptr) add_v[nt] += *reinterpret_cast<const f32x4*>(a.temb + (size_t)trow * a.temb_stride + co);
         }
     }
+    auto epilogue = [&]() {
+        f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (ntile0 + nt) * 16 + kq * 4;
+            const f32x4 add = add_v[nt];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int pp = (wm * MT + mt) * 16 + p16;
+                const int py = pp / TW, px = pp - py * TW;
+                const int oy = oy0 + py, ox = ox0 + px;
+                if (oy < a.OH && ox < a.OW) {
+                    const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
+                    f32x4 v = acc[mt][nt] * a.out_scale + add;
+                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+                    *reinterpret_cast<f32x4*>(a.out + o) = v;
+                    ssum[nt] += v; ssq[nt] += v * v;
+                }
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (a.stat_partial != nullptr) {
+            // fold the 16 pixel lanes (fixed order -> deterministic), lanes p16 == 0 publish 4 channels each
+            const int row = trem * WM + wm;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
+                if (p16 == 0) {
+                    const int co = (ntile0 + nt) * 16 + kq * 4;
+                    float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
+                    *reinterpret_cast<f32x4*>(pr) = ssum[nt];
+                    *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
+                }
+            }
+        }
+    };
+
+    // ---- tile / chunk loop -----------------------------------------------------------------------
+    for (;;) {
+        const int next_tile = trem + a.wgs_per_img;
+        const bool has_next_tile = next_tile < tiles_per_img;
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more_in_tile = (c + 1 < nchunks);
+            const bool more = more_in_tile || has_next_tile;
+            const int next_chunk = more_in_tile ? c + 1 : 0;
+            const bool full = (CB == 2) && (2 * c + 1 < nblk);
+            // the staging geometry switches to the next tile right before its first chunk is requested
+            // (every transform of the current tile is done by then; the epilogue does not use it)
+            if (!more_in_tile && has_next_tile) set_tile(next_tile);
+            auto run_chunk = [&](auto more_t) {
+                constexpr bool MORE = decltype(more_t)::value;
+                if (full) {
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        const int dy = tap / KS, dx = tap - dy * KS;
+                        int xo[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_full[mt] + (dy * IW + dx) * 32;
+                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, next_chunk, xo);
+                        else                              k_step(std::false_type{}, MORE && tap == 0, next_chunk, xo);
+                    }
+                } else {
+#pragma unroll
+                    for (int hs = 0; hs < HSTEPS; ++hs) {
+                        const int t0 = 2 * hs, t1 = (2 * hs + 1 < TAPS) ? 2 * hs + 1 : 0;   // padded half has zero weights
+                        const int o0 = ((t0 / KS) * IW + (t0 % KS)) * 32, o1 = ((t1 / KS) * IW + (t1 % KS)) * 32;
+                        const int to = (kq >> 1) ? o1 : o0;
+                        int xo[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
+                        if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, next_chunk, xo);
+                        else                            k_step(std::false_type{}, MORE && hs == 0, next_chunk, xo);
+                    }
+                }
+            };
+            if (more) {
+                run_chunk(std::true_type{});
+                // every wave is done reading the image, and A(next) (older than the last min(nsteps-1, D)
+                // weight groups) has landed, before the image is rewritten
+                const int nsteps = full ? TAPS : HSTEPS;
+                if (nsteps - 1 >= D) wait_vm_and_barrier<D * PPW>();
+                else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
+                else wait_vm_and_barrier<0>();
+                if (!more_in_tile) {                    // tile finished: store it, move to the next one
+                    epilogue();
+                    trem = next_tile;
+                    oy0 = (trem / a.tiles_x) * TH; ox0 = (trem % a.tiles_x) * TW;
+                }
+                transform(next_chunk);
+                if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            } else {
+                run_chunk(std::false_type{});
+            }
+        }
+        if (!has_next_tile) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight refills issued past the last step
+    epilogue();
 }
 
 // ------------------------------------------------------------------------------ dispatch
@@ -437,7 +468,15 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     a.debug = dbg;
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + G::TH - 1) / G::TH;
-    dim3 grid(a.B * a.tiles_x * a.tiles_y, a.Cout / (WN * NT * 16));
+    const int tiles = a.tiles_x * a.tiles_y, ny = a.Cout / (WN * NT * 16);
+    // ~3 resident workgroups per CU; a sample's tiles are dealt evenly to its workgroups
+    static const int target_wgs = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 768;
+    int per_img = target_wgs / (a.B * ny);
+    if (per_img < 1) per_img = 1;
+    if (per_img > tiles) per_img = tiles;
+    const int tiles_per_wg = (tiles + per_img - 1) / per_img;
+    a.wgs_per_img = (tiles + tiles_per_wg - 1) / tiles_per_wg;
+    dim3 grid(a.B * a.wgs_per_img, ny);
     if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
         if (a.C0 + a.C1 > G::MAX_CIN) return hipErrorInvalidValue;
         if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets

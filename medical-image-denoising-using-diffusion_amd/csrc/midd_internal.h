@@ -35,6 +35,7 @@ struct ConvArgs {
     float* stat_partial;
     int stat_rows;
     int tiles_x, tiles_y;
+    int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
 };
 
 struct ConvTile {           // which template instance to launch
