@@ -31,7 +31,21 @@ from midd_amd.weights import make_state_dict, synthetic_xray  # noqa: E402
 GF_PER_IMAGE_STEP = {256: 91.669e9, 512: 424.656e9}
 BYTES_PER_IMAGE_STEP_F32 = {256: 846.2e6, 512: 3384.8e6}
 PEAK_MFMA_F32 = 157.3e12        # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_MFMA_F16 = 2.5e15          # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 PEAK_HBM = 8.0e12
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes
+    (profiles/r01b_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
+    corrections applied as MI355X_MICROARCH.md prescribes), or None."""
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kernel_name)
+        return k["hbm_bytes_per_launch"] if k else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(sd_np, cfg, size, noise_steps, iters):
@@ -69,6 +83,8 @@ def main():
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--noise-steps", type=int, default=50)
     ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--compute", default=None, choices=["f16x3", "f32"],
+                    help="MFMA arithmetic: split-fp16 x3 (default) or fp32-input MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,7 +104,7 @@ def main():
 
     cfg = UNetConfig()
     sd_np = make_state_dict(cfg, seed=42)                     # random-init weights of the architecture
-    model = UNetDiffusion()
+    model = UNetDiffusion(compute=args.compute)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     model = model.to(dev).eval()
     den = DiffusionDenoiser(model, noise_steps=args.noise_steps)
@@ -126,7 +142,8 @@ def main():
                   else f"denoised images/sec, {S}x{S} x{n_iters} DDIM steps",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (split-fp16 x3 MFMA, fp32 accumulate)" if model.compute == "f16x3" else "f32",
+        "data": "synthetic",
         "config": {"workload": f"batch={Bp}/GPU {S}x{S} grayscale, {n_iters}-iteration reverse loop "
                                f"(noise_steps={args.noise_steps}, inference_steps={args.inference_steps}), "
                                "random-init 12.8M-param UNet (BASELINE.json configs[1])",
@@ -143,11 +160,21 @@ def main():
         total_ms = sum(p["total_ms"] for p in prof)
         dom = max((p for p in prof if p["flops"] > 0), key=lambda p: p["total_ms"])
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3)
+        if model.compute == "f16x3":
+            # every fp32-equivalent product costs three fp16 MFMA products (hi*hi + hi*lo + lo*hi), so the
+            # attainable ALGORITHMIC rate is the dense fp16 MFMA peak / 3
+            peak, peak_note = PEAK_MFMA_F16 / 3, "2.5 PFLOP/s dense fp16 MFMA / 3 split passes"
+        else:
+            peak, peak_note = PEAK_MFMA_F32, "fp32-input MFMA dense peak"
+        traffic = pmc_traffic(dom["name"]) if (Bp == 8 and S == 256) else None
         result["roofline"] = {
-            "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": PEAK_MFMA_F32 / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32, "traffic": None,
+            "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": peak / 1e12,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "peak_note": peak_note,
             "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
             "alg_flops_per_launch": dom["flops"] / dom["launches"],
+            "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+            "alg_GBps": dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9,
+            "frac_hbm_peak": dom["bytes"] / (dom["total_ms"] * 1e-3) / PEAK_HBM,
             "share_of_kernel_time": dom["total_ms"] / total_ms,
         }
         gf = GF_PER_IMAGE_STEP.get(S)
@@ -155,6 +182,7 @@ def main():
             per_gpu_rate = (value / world) * n_iters          # image-steps per second per GPU
             result["whole_loop"] = {
                 "ref_graph_tflops": per_gpu_rate * gf / 1e12, "frac_mfma_f32_peak": per_gpu_rate * gf / PEAK_MFMA_F32,
+                "frac_mfma_f16x3_peak": per_gpu_rate * gf / (PEAK_MFMA_F16 / 3),
                 "alg_GBps": per_gpu_rate * BYTES_PER_IMAGE_STEP_F32[S] / 1e9,
                 "frac_hbm_peak": per_gpu_rate * BYTES_PER_IMAGE_STEP_F32[S] / PEAK_HBM,
             }
