@@ -86,7 +86,7 @@ struct Conv16Geom {
     static constexpr int IH = (TH - 1) * STRIDE + KS;
     static constexpr int IW = (TW - 1) * STRIDE + KS;
     static constexpr int NPIX = IH * IW;
-    static constexpr int CB = CONV16_CB;                            // 16-channel blocks per chunk
+    static constexpr int CB = conv16_cb(KS);                        // 16-channel blocks per chunk
     static constexpr int QPP = 4 * CB;                              // 16-byte slots per halo pixel and chunk
     static constexpr int NSLOT = NPIX * QPP;
     static constexpr int APW = (NSLOT + NTHREADS - 1) / NTHREADS;   // activation DMA pieces per wave and chunk
@@ -101,7 +101,7 @@ struct Conv16Geom {
     // weight steps resident in LDS (prefetch distance RING-1): L2->LDS latency is ~1-2k cycles under
     // load, a step is only 150-600 MFMA cycles, so take as many slots as fit in half the LDS (two
     // workgroups per CU), between 2 and 6.
-    static constexpr int LDS_TARGET = (CB == 1 ? 52 : 80) * 1024;   // three / two workgroups per CU
+    static constexpr int LDS_TARGET = 52 * 1024;                    // three workgroups per CU
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > 6 ? 6 : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
@@ -514,10 +514,11 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int nw = d.wm * d.wn, nthreads = nw * 64;
     const int bm = d.wm * d.mt * 16, th = bm / d.tw;
     const int ih = (th - 1) * stride + ks, iw = (d.tw - 1) * stride + ks;
-    const int npix = ih * iw, apw = (npix * 4 * CONV16_CB + nthreads - 1) / nthreads;
+    const int cb = conv16_cb(ks);
+    const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
-    const long fixed = (long)apw * nthreads * 16 + 2L * CONV16_CB * npix * 32 + 2 * 512 * 4;
-    long ring = ((CONV16_CB == 1 ? 52 : 80) * 1024 - fixed) / (wpieces * 1024);
+    const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + 2 * 512 * 4;
+    long ring = (52 * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > 6 ? 6 : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;

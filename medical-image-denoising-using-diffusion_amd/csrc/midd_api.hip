@@ -345,7 +345,7 @@ static std::vector<float> pack_conv_f16x3(const float* w, int Cout, int Cin, int
             }
         ++step;
     };
-    if (CONV16_CB == 1) {
+    if (conv16_cb(KS) == 1) {
         for (int blk = 0; blk < nblk; ++blk)
             for (int hs = 0; hs < (taps + 1) / 2; ++hs) emit(blk, blk, 2 * hs, 2 * hs + 1);
     } else {
@@ -833,6 +833,13 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             (void)hipEventRecord(ev_b, s);
             mi_plan::Span sp; sp.a = ev_a; sp.b = ev_b;
             op_work(p, g, o, &sp.name, &sp.flops, &sp.bytes);
+            static const bool per_op = getenv("MIDD_PROFILE_PER_OP") != nullptr;      // one entry per op instead of per symbol
+            if (per_op) {
+                char tag[96];
+                snprintf(tag, sizeof(tag), "op%03d %dx%d c%d+%d->%d k%d s%d | ", (int)(&o - g->ops.data()), o.dst.H, o.dst.W,
+                         o.s0.C, o.has_s1 ? o.s1.C : 0, o.dst.C, o.ks, o.stride);
+                sp.name = std::string(tag) + sp.name;
+            }
             p->spans.push_back(std::move(sp));
         }
     }
@@ -1017,6 +1024,7 @@ extern "C" int mi_profile_end(mi_plan* plan, mi_profile_entry* out, int max_entr
     plan->spans.clear();
     *n_entries = (int)order.size();
     for (int i = 0; i < (int)order.size() && i < max_entries && out; ++i) out[i] = agg[order[i]];
+    if ((int)order.size() > max_entries) *n_entries = max_entries;
     return MI_OK;
 }
 

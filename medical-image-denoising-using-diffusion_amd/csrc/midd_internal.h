@@ -54,17 +54,15 @@ int conv_stat_rows(const ConvTile& t, int OH, int OW);
 bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 // 16-channel blocks staged per K chunk of the f16x3 kernel (shared with the host packer).
-//   2: 32 channels per chunk, one tap per MFMA step (a trailing odd block pairs two taps per step)
-//   1: 16 channels per chunk, two taps per step everywhere: 10 % more MFMA slots for 3x3, but half
-//      the activation LDS, i.e. one more resident workgroup per CU to overlap load/compute/store
-#ifndef MIDD_CONV16_CB
-#define MIDD_CONV16_CB 1
-#endif
-constexpr int CONV16_CB = MIDD_CONV16_CB;
+//   3x3: 1 -> 16 channels per chunk, two taps per MFMA step (10 % padded MFMA slots, but half the
+//             activation LDS of a 32-channel chunk, i.e. three resident workgroups per CU)
+//   1x1: 2 -> 32 channels per chunk and step (no halo, so the image is small; halves the number of
+//             chunk hand-overs, which dominate a 1x1)
+__host__ __device__ constexpr int conv16_cb(int ks) { return ks == 1 ? 2 : 1; }
 // number of 32-wide K steps the f16x3 kernel walks for (Cin, taps)
 __host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
     const int nblk = Cin / 16;
-    if (CONV16_CB == 1) return nblk * ((taps + 1) / 2);
+    if (conv16_cb(taps == 1 ? 1 : 3) == 1) return nblk * ((taps + 1) / 2);
     const int full = nblk / 2, half = nblk & 1;
     return full * taps + half * ((taps + 1) / 2);
 }

@@ -239,11 +239,12 @@ class UNetDiffusion(nn.Module):
     def profile_end(self):
         """-> list of dicts {name, launches, total_ms, flops, bytes}, one per kernel symbol."""
         with self._lock:
-            buf = (native.ProfileEntry * 64)()
+            cap = 512
+            buf = (native.ProfileEntry * cap)()
             n = C.c_int()
-            native.check(native.lib().mi_profile_end(self._plan, buf, 64, C.byref(n)))
+            native.check(native.lib().mi_profile_end(self._plan, buf, cap, C.byref(n)))
             return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
-                         flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(min(n.value, 64))]
+                         flops=float(buf[i].flops), bytes=float(buf[i].bytes)) for i in range(min(n.value, cap))]
 
     def workspace_bytes(self, B: int, H: int, W: int) -> int:
         with self._lock, torch.cuda.device(self._device()):
