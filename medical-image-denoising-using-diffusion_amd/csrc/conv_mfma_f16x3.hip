@@ -101,15 +101,26 @@ struct Conv16Geom {
     // weight steps resident in LDS (prefetch distance RING-1): L2->LDS latency is ~1-2k cycles under
     // load, a step is only 150-600 MFMA cycles, so take as many slots as fit in half the LDS (two
     // workgroups per CU), between 2 and 6.
-    static constexpr int LDS_TARGET = 52 * 1024;                    // three workgroups per CU
+#ifndef MIDD_LDS_TARGET_KB
+#define MIDD_LDS_TARGET_KB 52
+#endif
+#ifndef MIDD_RING_MAX
+#define MIDD_RING_MAX 6
+#endif
+    static constexpr int LDS_TARGET = MIDD_LDS_TARGET_KB * 1024;    // 52 KB: three workgroups per CU
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
-    static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > 6 ? 6 : ring_fit);
+    static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
     static_assert(BM % TW == 0, "tile");
 };
 
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64)
+#ifndef MIDD_CONV16_WAVES_PER_SIMD
+#define MIDD_CONV16_WAVES_PER_SIMD 3
+#endif
+// the register budget is capped so that as many workgroups as the LDS target allows are resident
+// (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? MIDD_CONV16_WAVES_PER_SIMD : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
@@ -352,10 +363,12 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             if (a.temb != nullptr) add_v[nt] += *reinterpret_cast<const f32x4*>(a.temb + (size_t)trow * a.temb_stride + co);
         }
     }
-    auto epilogue = [&]() {
-        f32x4 ssum[NT], ssq[NT];
+    // GroupNorm partial sums of the output run across ALL tiles of this (persistent) workgroup and are
+    // published once at the end: one row per (workgroup, wave) instead of one per (tile, wave)
+    f32x4 ssum[NT], ssq[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    auto epilogue = [&]() {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = (ntile0 + nt) * 16 + kq * 4;
@@ -375,19 +388,20 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (a.stat_partial != nullptr) {
-            // fold the 16 pixel lanes (fixed order -> deterministic), lanes p16 == 0 publish 4 channels each
-            const int row = trem * WM + wm;
+    };
+    auto publish_stats = [&]() {
+        if (a.stat_partial == nullptr) return;
+        // fold the 16 pixel lanes (fixed order -> deterministic), lanes p16 == 0 publish 4 channels each
+        const int row = (blockIdx.x - b * a.wgs_per_img) * WM + wm;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
-                if (p16 == 0) {
-                    const int co = (ntile0 + nt) * 16 + kq * 4;
-                    float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
-                    *reinterpret_cast<f32x4*>(pr) = ssum[nt];
-                    *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
-                }
+            for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
+            if (p16 == 0) {
+                const int co = (ntile0 + nt) * 16 + kq * 4;
+                float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
+                *reinterpret_cast<f32x4*>(pr) = ssum[nt];
+                *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
             }
         }
     };
@@ -457,9 +471,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight refills issued past the last step
     epilogue();
+    publish_stats();
 }
 
 // ------------------------------------------------------------------------------ dispatch
+static int conv16_wgs_per_img(int tiles, int B, int ny);
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
@@ -468,14 +484,8 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     a.debug = dbg;
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + G::TH - 1) / G::TH;
-    const int tiles = a.tiles_x * a.tiles_y, ny = a.Cout / (WN * NT * 16);
-    // ~3 resident workgroups per CU; a sample's tiles are dealt evenly to its workgroups
-    static const int target_wgs = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 768;
-    int per_img = target_wgs / (a.B * ny);
-    if (per_img < 1) per_img = 1;
-    if (per_img > tiles) per_img = tiles;
-    const int tiles_per_wg = (tiles + per_img - 1) / per_img;
-    a.wgs_per_img = (tiles + tiles_per_wg - 1) / tiles_per_wg;
+    const int ny = a.Cout / (WN * NT * 16);
+    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny);
     dim3 grid(a.B * a.wgs_per_img, ny);
     if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
         if (a.C0 + a.C1 > G::MAX_CIN) return hipErrorInvalidValue;
@@ -487,14 +497,26 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     }
 }
 
-int conv_stat_rows(const ConvTile& t, int OH, int OW) {
+// ~3 resident workgroups per CU; a sample's tiles are dealt evenly to its persistent workgroups
+static int conv16_wgs_per_img(int tiles, int B, int ny) {
+    static const int target_wgs = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 768;
+    int per_img = target_wgs / (B * ny);
+    if (per_img < 1) per_img = 1;
+    if (per_img > tiles) per_img = tiles;
+    const int tiles_per_wg = (tiles + per_img - 1) / per_img;
+    return (tiles + tiles_per_wg - 1) / tiles_per_wg;
+}
+
+int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout) {
     const int bm = t.wm * t.mt * 16, th = bm / t.tw;
-    return ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th) * t.wm;
+    const int tiles = ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th);
+    if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16)) * t.wm;
+    return tiles * t.wm;
 }
 
 #define MIDD_CONV16_TILES(X)                  \
     /*  tw  mt nt wm wn */                    \
-    X(16, 4, 3, 4, 1) X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) \
+    X(16, 4, 3, 4, 1) X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) X(16, 1, 3, 8, 1) \
     X(16, 4, 3, 2, 2) X(16, 2, 3, 2, 2) X(16, 1, 3, 2, 2) X(8, 1, 3, 1, 2) \
     X(16, 4, 3, 1, 3) X(16, 2, 3, 1, 3) X(8, 1, 3, 1, 3)                   \
     X(16, 4, 3, 1, 4) X(16, 2, 3, 1, 4) X(8, 2, 3, 1, 4) X(8, 1, 3, 1, 4)  \
@@ -518,8 +540,8 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
     const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + 2 * 512 * 4;
-    long ring = (52 * 1024 - fixed) / (wpieces * 1024);
-    ring = ring < 2 ? 2 : (ring > 6 ? 6 : ring);
+    long ring = (MIDD_LDS_TARGET_KB * 1024 - fixed) / (wpieces * 1024);
+    ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
 }
@@ -545,7 +567,9 @@ bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvT
         const bool wasteful = covered * 4 > (long)OH * OW * 5;
         // enough workgroups first; then the pixels one weight fetch is shared over (the weight stream
         // from L2 is what starves small tiles), then the couts one activation staging is shared over
-        const long share = pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm;
+        static const long w8_below = getenv("MIDD_W8_BELOW") ? atol(getenv("MIDD_W8_BELOW")) : 0;
+        if (d.wm == 8 && wgs >= w8_below) continue;          // 8-wave tiles only where one workgroup per CU is all there is
+        const long share = (pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm) + (d.wm == 8 ? 4 : 0);
         const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }
     }

@@ -117,14 +117,15 @@ int gn_pick_nsplit(int B, int HW, int C) {
 // outputs), from chan_partial_kernel.  gn_from_partial_kernel folds them in a fixed order in
 // fp64 and emits scale/shift; one block per (group, sample).  Channels are resolved one by one
 // to (source, local channel), so groups may straddle the torch.cat seam (cddpm up path).
-__global__ __launch_bounds__(GN_THREADS)
+constexpr int GNF_THREADS = 256;              // many row lanes: the row loop is L2-latency bound
+__global__ __launch_bounds__(GNF_THREADS)
 void gn_from_partial_kernel(const GnFromPartialArgs a) {
-    __shared__ double red[GN_THREADS][2];
+    __shared__ double red[GNF_THREADS][2];
     __shared__ float s_mr[2];
     const int C = a.C0 + a.C1;
     const int cg = C / GN_GROUPS_;
     const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int nrl = GN_THREADS / cg;                  // row lanes
+    const int nrl = GNF_THREADS / cg;                 // row lanes
     const int ci = tid % cg, rl = tid / cg;
     double s1 = 0, s2 = 0;
     if (rl < nrl) {
@@ -179,8 +180,8 @@ void gn_from_partial_kernel(const GnFromPartialArgs a) {
 
 hipError_t gn_from_partial_launch(const GnFromPartialArgs& a, hipStream_t s) {
     const int C = a.C0 + a.C1;
-    if (C % GN_GROUPS_ || C / GN_GROUPS_ > GN_THREADS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gn_from_partial_kernel, dim3(GN_GROUPS_, a.B), dim3(GN_THREADS), 0, s, a);
+    if (C % GN_GROUPS_ || C / GN_GROUPS_ > GNF_THREADS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_from_partial_kernel, dim3(GN_GROUPS_, a.B), dim3(GNF_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -553,7 +553,7 @@ struct Builder {
                             : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
         if (want_stats) {
-            dst.stat_rows = conv_stat_rows(o.tile, dst.H, dst.W);
+            dst.stat_rows = conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C);
             dst.stat_off = bump.take((size_t)B * dst.stat_rows * 2 * dst.C * sizeof(float));
             o.want_stats = true;
         }

@@ -48,7 +48,7 @@ enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
 bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
 hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 // rows of the fused-statistics buffer one launch with this tile writes per image
-int conv_stat_rows(const ConvTile& t, int OH, int OW);
+int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout);
 
 // split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
 bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
