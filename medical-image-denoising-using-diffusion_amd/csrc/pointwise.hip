@@ -15,10 +15,14 @@ namespace midd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_pw(float v) { return v / (1.0f + expf(-v)); }
+// x * sigmoid(x) on v_exp_f32 / v_rcp_f32 (~1 ulp each)
+__device__ __forceinline__ float silu_pw(float v) {
+    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
 
 // ------------------------------------------------------------------------------ in_conv
-// thread = (pixel, 4 consecutive couts); weights [9][2ic][Cout] and bias staged in LDS.
+// thread = (pixel, 16 consecutive couts): the 18 input taps are loaded once per 16 outputs; weights
+// [9][2ic][Cout] and bias staged in LDS; a pixel's lanes write one contiguous 4*Cout-byte run.
 __global__ __launch_bounds__(256)
 void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ w,
                     const float* __restrict__ bias, float* __restrict__ out, int B, int ic, int H, int W, int Cout) {
@@ -26,16 +30,18 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
     const int nw = 9 * 2 * ic * Cout;
     for (int i = threadIdx.x; i < nw + Cout; i += 256) wl[i] = (i < nw) ? w[i] : bias[i - nw];
     __syncthreads();
-    const int CQ = Cout >> 2;
-    const long total = (long)B * H * W * CQ;
+    const int CG = Cout >> 4;                     // groups of 16 couts
+    const long total = (long)B * H * W * CG;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
-    const int cq = (int)(gid % CQ);
-    const long pix = gid / CQ;
+    const int cg = (int)(gid % CG);
+    const long pix = gid / CG;
     const int ox = (int)(pix % W);
     const int oy = (int)((pix / W) % H);
     const int b = (int)(pix / ((long)W * H));
-    f32x4 acc = *reinterpret_cast<const f32x4*>(&wl[nw + cq * 4]);
+    f32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = *reinterpret_cast<const f32x4*>(&wl[nw + cg * 16 + k * 4]);
     for (int ci = 0; ci < 2 * ic; ++ci) {
         const float* plane = (ci < ic) ? x + ((size_t)b * ic + ci) * H * W
                                        : cond + ((size_t)b * ic + (ci - ic)) * H * W;
@@ -48,17 +54,20 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
                 const int gx = ox + dx - 1;
                 if (gx < 0 || gx >= W) continue;
                 const float v = plane[(size_t)gy * W + gx];
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[((dy * 3 + dx) * 2 * ic + ci) * Cout + cq * 4]);
-                acc += v * wv;
+                const float* wr = &wl[((dy * 3 + dx) * 2 * ic + ci) * Cout + cg * 16];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += v * *reinterpret_cast<const f32x4*>(wr + k * 4);
             }
         }
     }
-    *reinterpret_cast<f32x4*>(out + (size_t)pix * Cout + cq * 4) = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(out + (size_t)pix * Cout + cg * 16 + k * 4) = acc[k];
 }
 
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w, const float* bias, float* out,
                           int B, int ic, int H, int W, int Cout, hipStream_t s) {
-    const long total = (long)B * H * W * (Cout / 4);
+    if (Cout % 16) return hipErrorInvalidValue;
+    const long total = (long)B * H * W * (Cout / 16);
     const size_t lds = (size_t)(9 * 2 * ic * Cout + Cout) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(in_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s,
