@@ -59,18 +59,24 @@ void attention_prep_kernel(const float* __restrict__ qkv, _Float16* __restrict__
             *reinterpret_cast<half4*>(kl + (size_t)key * D + dq * 4) = lo;
         }
     }
-    // V^T: thread = (d, key pair) -> one 4-byte store per plane; keys >= N are written as zeros
-    for (int idx = threadIdx.x; idx < 32 * D; idx += 256) {
-        const int kp = idx / D, d = idx - kp * D;
-        const int k0 = key0 + 2 * kp;
-        float v0 = 0.f, v1 = 0.f;
-        if (k0 < N) v0 = base[(size_t)k0 * C3 + vcol + d];
-        if (k0 + 1 < N) v1 = base[(size_t)(k0 + 1) * C3 + vcol + d];
-        half2v hi, lo;
-        { _Float16 h_, l_; split1(v0 * A16_QKV_SCALE, h_, l_); hi[0] = h_; lo[0] = l_; }
-        { _Float16 h_, l_; split1(v1 * A16_QKV_SCALE, h_, l_); hi[1] = h_; lo[1] = l_; }
-        *reinterpret_cast<half2v*>(vh + (size_t)d * Npad + k0) = hi;
-        *reinterpret_cast<half2v*>(vl + (size_t)d * Npad + k0) = lo;
+    // V^T through an LDS transpose: coalesced float4 reads along d, then each thread writes 8 consecutive
+    // keys (16 bytes) of one d-row per plane; keys >= N are written as zeros
+    __shared__ float vt[64][128 + 1];
+    for (int idx = threadIdx.x; idx < 64 * (D / 4); idx += 256) {
+        const int kk = idx / (D / 4), dq = idx % (D / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (key0 + kk < N) v = *reinterpret_cast<const f32x4*>(base + (size_t)(key0 + kk) * C3 + vcol + dq * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vt[kk][dq * 4 + e] = v[e] * A16_QKV_SCALE;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < D * 8; idx += 256) {
+        const int d = idx >> 3, k8 = idx & 7;
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 h_, l_; split1(vt[k8 * 8 + j][d], h_, l_); hi[j] = h_; lo[j] = l_; }
+        *reinterpret_cast<half8*>(vh + (size_t)d * Npad + key0 + k8 * 8) = hi;
+        *reinterpret_cast<half8*>(vl + (size_t)d * Npad + key0 + k8 * 8) = lo;
     }
 }
 
