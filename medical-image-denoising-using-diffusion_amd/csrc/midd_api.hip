@@ -107,8 +107,10 @@ struct mi_plan {
     hipStream_t gstream = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     // two half-batches on two streams (mi_denoise): side stream + fork / phase / join events
-    hipStream_t sstream = nullptr;
-    hipEvent_t sev_fork = nullptr, sev_phase = nullptr, sev_join = nullptr;
+    static const int MAX_PARTS = 4;
+    hipStream_t sstream[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};        // [0] unused (caller's stream)
+    hipEvent_t sev_fork = nullptr, sev_phase[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr},
+               sev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex side_mu;
     // profiling (mi_profile_begin/end)
     bool profiling = false;
@@ -694,19 +696,23 @@ static int get_program(mi_plan* p, int B, int H, int W, Program** out) {
     return MI_OK;
 }
 
-static bool split_enabled(int B) {
-    static const int split = getenv("MIDD_SPLIT") ? atoi(getenv("MIDD_SPLIT")) : 1;
-    return split != 0 && B >= 4 && B % 2 == 0;
+// number of independent sub-batches mi_denoise runs side by side (MIDD_SPLIT = 1 | 2 | 4; default 2)
+static int split_parts(int B) {
+    static const int want = getenv("MIDD_SPLIT") ? atoi(getenv("MIDD_SPLIT")) : 2;
+    int parts = (want >= 4) ? 4 : (want >= 2 ? 2 : 1);
+    while (parts > 1 && (B % parts || B / parts < 2)) parts /= 2;
+    return parts;
 }
 
 extern "C" size_t mi_workspace_bytes(mi_plan* plan, int B, int H, int W) {
     Program* g = nullptr;
     if (!plan || get_program(plan, B, H, W, &g)) return 0;
     size_t need = g->bytes;
-    if (split_enabled(B)) {                      // mi_denoise runs two half-batches side by side
+    const int parts = split_parts(B);            // mi_denoise runs sub-batches side by side
+    if (parts > 1) {
         Program* gh = nullptr;
-        if (get_program(plan, B / 2, H, W, &gh)) return 0;
-        if (2 * gh->bytes > need) need = 2 * gh->bytes;
+        if (get_program(plan, B / parts, H, W, &gh)) return 0;
+        if (parts * gh->bytes > need) need = parts * gh->bytes;
     }
     return need;
 }
@@ -767,7 +773,7 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
 }
 
 static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s,
-                       hipEvent_t mid_event = nullptr) {
+                       hipEvent_t mid_event = nullptr, int mid_div = 2) {
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
@@ -845,7 +851,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             }
         }
         if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
-        if (mid_event && (size_t)(&o - g->ops.data()) == g->ops.size() / 2) (void)hipEventRecord(mid_event, s);
+        if (mid_event && (size_t)(&o - g->ops.data()) == g->ops.size() / mid_div) (void)hipEventRecord(mid_event, s);
         if (p->profiling) {
             (void)hipEventRecord(ev_b, s);
             mi_plan::Span sp; sp.a = ev_a; sp.b = ev_b;
@@ -980,40 +986,47 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         if (rc != MI_EAGAIN_EAGER) return rc;             // capture unavailable: fall through to eager launches
     }
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, s));   // x = noisy_img.clone()
-    if (split_enabled(B) && !plan->profiling && n_iters > 0) {
-        // Images are independent: the batch runs as two half-batches on two streams, the second one
-        // started half a forward late, so that one half's latency-bound low-resolution layers (one
-        // workgroup per CU at B=8) share the chip with the other half's HBM-bound high-resolution layers.
+    const int parts = split_parts(B);
+    if (parts > 1 && !plan->profiling && n_iters > 0) {
+        // Images are independent: the batch runs as `parts` sub-batches on as many streams, each started
+        // 1/parts of a forward after the previous one, so that one part's latency-bound low-resolution
+        // layers (one workgroup per CU at B=8) share the chip with another part's HBM-bound high-resolution
+        // layers.
         Program* gh = nullptr;
-        if ((rc = get_program(plan, B / 2, H, W, &gh))) return rc;
-        if (workspace_bytes < 2 * gh->bytes) return fail(MI_ENOMEM, "workspace too small for the split run: need %zu bytes", 2 * gh->bytes);
+        if ((rc = get_program(plan, B / parts, H, W, &gh))) return rc;
+        if (workspace_bytes < parts * gh->bytes) return fail(MI_ENOMEM, "workspace too small for the split run: need %zu bytes", parts * gh->bytes);
         std::lock_guard<std::mutex> lk(plan->side_mu);
-        if (!plan->sstream) {
-            HIPCHK(hipStreamCreateWithFlags(&plan->sstream, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&plan->sev_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&plan->sev_phase, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&plan->sev_join, hipEventDisableTiming));
+        if (!plan->sev_fork) HIPCHK(hipEventCreateWithFlags(&plan->sev_fork, hipEventDisableTiming));
+        for (int h = 1; h < parts; ++h) {
+            if (!plan->sstream[h]) {
+                HIPCHK(hipStreamCreateWithFlags(&plan->sstream[h], hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&plan->sev_join[h], hipEventDisableTiming));
+            }
+            if (!plan->sev_phase[h - 1]) HIPCHK(hipEventCreateWithFlags(&plan->sev_phase[h - 1], hipEventDisableTiming));
         }
-        hipStream_t st[2] = {s, plan->sstream};
-        char* wsh[2] = {ws, ws + gh->bytes};
-        const size_t half = img_elems / 2;
+        const size_t part = img_elems / parts;
         HIPCHK(hipEventRecord(plan->sev_fork, s));
-        HIPCHK(hipStreamWaitEvent(plan->sstream, plan->sev_fork, 0));
+        for (int h = 1; h < parts; ++h) HIPCHK(hipStreamWaitEvent(plan->sstream[h], plan->sev_fork, 0));
         for (int i = 0; i < n_iters; ++i) {
             const int t = t_list[i];
-            for (int h = 0; h < 2; ++h) {
-                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(wsh[h] + gh->trow_off), t, B / 2, st[h]));
+            for (int h = 0; h < parts; ++h) {
+                hipStream_t sh = h ? plan->sstream[h] : s;
+                char* wsh = ws + (size_t)h * gh->bytes;
+                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(wsh + gh->trow_off), t, B / parts, sh));
                 StepIO io{};
-                io.x = x_out + h * half; io.cond = noisy + h * half; io.eps_out = nullptr; io.x_update = x_out + h * half;
+                io.x = x_out + h * part; io.cond = noisy + h * part; io.eps_out = nullptr; io.x_update = x_out + h * part;
                 coef(t, &io.c1, &io.c2, &io.c3);
-                io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems + h * half : nullptr;
+                io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems + h * part : nullptr;
                 io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
-                if (i == 0 && h == 1) HIPCHK(hipStreamWaitEvent(st[1], plan->sev_phase, 0));      // phase offset
-                if ((rc = run_program(plan, gh, io, wsh[h], st[h], (i == 0 && h == 0) ? plan->sev_phase : nullptr))) return rc;
+                if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
+                hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
+                if ((rc = run_program(plan, gh, io, wsh, sh, mid, parts))) return rc;
             }
         }
-        HIPCHK(hipEventRecord(plan->sev_join, plan->sstream));
-        HIPCHK(hipStreamWaitEvent(s, plan->sev_join, 0));
+        for (int h = 1; h < parts; ++h) {
+            HIPCHK(hipEventRecord(plan->sev_join[h], plan->sstream[h]));
+            HIPCHK(hipStreamWaitEvent(s, plan->sev_join[h], 0));
+        }
         return MI_OK;
     }
     for (int i = 0; i < n_iters; ++i) {
@@ -1090,9 +1103,11 @@ extern "C" void mi_plan_destroy(mi_plan* plan) {
     if (plan->gev_out) (void)hipEventDestroy(plan->gev_out);
     if (plan->gstream) (void)hipStreamDestroy(plan->gstream);
     if (plan->sev_fork) (void)hipEventDestroy(plan->sev_fork);
-    if (plan->sev_phase) (void)hipEventDestroy(plan->sev_phase);
-    if (plan->sev_join) (void)hipEventDestroy(plan->sev_join);
-    if (plan->sstream) (void)hipStreamDestroy(plan->sstream);
+    for (int i = 0; i < mi_plan::MAX_PARTS; ++i) {
+        if (plan->sev_phase[i]) (void)hipEventDestroy(plan->sev_phase[i]);
+        if (plan->sev_join[i]) (void)hipEventDestroy(plan->sev_join[i]);
+        if (plan->sstream[i]) (void)hipStreamDestroy(plan->sstream[i]);
+    }
     if (plan->wdev) (void)hipFree(plan->wdev);
     if (plan->ttab) (void)hipFree(plan->ttab);
     delete plan;
