@@ -168,19 +168,19 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const size_t wstep_bytes = (size_t)ntiles_total * 2048;
     const int lane16 = lane * 16;
     int wr_step = 0, wr_slot = 0;                         // next step to fetch / the ring slot it goes to
+    const char* wr_src = wbase;                           // = wbase + wr_step * wstep_bytes, kept incrementally
     auto issue_w = [&]() {
-        if (a.debug & 1) return;
         char* slot = wring + wr_slot * WSLICE;
-        const char* src = wbase + (size_t)wr_step * wstep_bytes;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             // WM == 1: every wave owns a distinct cout slice, so it fetches exactly the pieces it
             // reads itself (no cross-wave hand-off, no barrier per step); otherwise round-robin.
             int piece = (WM == 1) ? wave * PPW + i : wave + i * NW;
             if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place
-            dma16(src + piece * 1024 + lane16, slot + piece * 1024);
+            dma16(wr_src + piece * 1024 + lane16, slot + piece * 1024);
         }
-        wr_step = (wr_step + 1 == total_steps) ? 0 : wr_step + 1;   // cyclic: step 0 of the next tile follows the last
+        ++wr_step; wr_src += wstep_bytes;
+        if (wr_step == total_steps) { wr_step = 0; wr_src = wbase; }   // cyclic: step 0 of the next tile follows the last
         wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
     };
 
@@ -207,7 +207,6 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // Lanes with nothing to fetch (padding, unused slots, missing second block) read a valid
     // dummy address; transform() writes zeros / nothing for them.
     auto issue_a = [&](int c) {
-        if (a.debug & 2) return;
         const int blk = min(CB * c + sblk, nblk - 1);
         const int ch = (blk << 4) + (q8 & 3) * 4;
         const float* src; unsigned cs4, coff;
@@ -222,7 +221,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     };
     auto transform = [&](int c) {
         const int blk = CB * c + sblk;
-        if (blk >= nblk || (a.debug & 16)) return;
+        if (blk >= nblk) return;
         const int ch = (blk << 4) + (q8 & 3) * 4;
         // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
         f32x4 sc = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -305,20 +304,22 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     }
 
     int rd_slot = 0;
-    auto mfma_step = [&](const int (&xo)[MT]) {
-        const char* wslot = wring + rd_slot * WSLICE + wfrag_off;
-        rd_slot = (rd_slot + 1 == RING) ? 0 : rd_slot + 1;
-        if (a.debug & 4) return;
-        half8 wh[NT], wl[NT], xh[MT], xl[MT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
-            wl[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
-        }
+    half8 xh[MT], xl[MT];
+    auto load_x = [&](const int (&xo)[MT]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             xh[mt] = *reinterpret_cast<const half8*>(img + xo[mt]);
             xl[mt] = *reinterpret_cast<const half8*>(img + xo[mt] + PLANE);
+        }
+    };
+    auto mfma_step = [&]() {
+        const char* wslot = wring + rd_slot * WSLICE + wfrag_off;
+        rd_slot = (rd_slot + 1 == RING) ? 0 : rd_slot + 1;
+        half8 wh[NT], wl[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
+            wl[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -337,18 +338,30 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
     };
 
-    auto k_step = [&](auto with_a, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
+    // The activation fragments of a step only depend on the chunk's image (published at the chunk
+    // boundary), not on the step's barrier: they are requested first, so their LDS latency overlaps the wait.
+    // `first` = first step of a chunk: its barrier is also the one that publishes the freshly transformed
+    // image, so the fragments are read after it (WM == 1 has a dedicated barrier after the transform).
+    auto k_step = [&](auto with_a, bool first, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
         constexpr bool WITH_A = decltype(with_a)::value;
         constexpr int N = (D - 1) * PPW + (WITH_A ? APW : 0);
-        if constexpr (WM == 1) {
-            // own weights only: the counted wait orders this wave's LDS reads behind its own DMA
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        const bool early = (WM == 1) || !first;
+        if (early) {
+            load_x(xo);
+            // LDS operations retire in order: "at most 2*MT outstanding" = everything older than the
+            // fragment reads just issued (the previous step's weight reads) is done
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(N), "n"(2 * MT) : "memory");
         } else {
-            wait_vm_and_barrier<N>();
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
         }
+        if constexpr (WM != 1) {           // WM == 1: own weights only, no cross-wave hand-off per step
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if (!early) load_x(xo);
         issue_w();
         if (first_with_more) issue_a(next_chunk);  // each thread already consumed its own raw slots
-        mfma_step(xo);
+        mfma_step();
     };
 
     // ---- epilogue (per tile) ------------------------------------------------------------------
@@ -427,8 +440,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                         int xo[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_full[mt] + (dy * IW + dx) * 32;
-                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, next_chunk, xo);
-                        else                              k_step(std::false_type{}, MORE && tap == 0, next_chunk, xo);
+                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, false, next_chunk, xo);
+                        else                              k_step(std::false_type{}, tap == 0, MORE && tap == 0, next_chunk, xo);
                     }
                 } else {
 #pragma unroll
@@ -439,8 +452,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                         int xo[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
-                        if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, next_chunk, xo);
-                        else                            k_step(std::false_type{}, MORE && hs == 0, next_chunk, xo);
+                        if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, false, next_chunk, xo);
+                        else                            k_step(std::false_type{}, hs == 0, MORE && hs == 0, next_chunk, xo);
                     }
                 }
             };
@@ -480,8 +493,6 @@ template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     ConvArgs a = a0;
-    static const int dbg = getenv("MIDD_DEBUG") ? atoi(getenv("MIDD_DEBUG")) : 0;
-    a.debug = dbg;
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + G::TH - 1) / G::TH;
     const int ny = a.Cout / (WN * NT * 16);
@@ -517,7 +528,7 @@ int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, i
 #define MIDD_CONV16_TILES(X)                  \
     /*  tw  mt nt wm wn */                    \
     X(16, 4, 3, 4, 1) X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) X(16, 1, 3, 8, 1) \
-    X(16, 4, 3, 2, 2) X(16, 2, 3, 2, 2) X(16, 1, 3, 2, 2) X(8, 1, 3, 1, 2) \
+    X(16, 2, 3, 4, 2) X(16, 4, 3, 2, 2) X(16, 2, 3, 2, 2) X(16, 1, 3, 2, 2) X(8, 1, 3, 1, 2) \
     X(16, 4, 3, 1, 3) X(16, 2, 3, 1, 3) X(8, 1, 3, 1, 3)                   \
     X(16, 4, 3, 1, 4) X(16, 2, 3, 1, 4) X(8, 2, 3, 1, 4) X(8, 1, 3, 1, 4)  \
     X(16, 4, 2, 4, 1) X(16, 2, 2, 4, 1) X(8, 1, 2, 2, 1)                   \
@@ -569,6 +580,8 @@ bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvT
         // from L2 is what starves small tiles), then the couts one activation staging is shared over
         static const long w8_below = getenv("MIDD_W8_BELOW") ? atol(getenv("MIDD_W8_BELOW")) : 0;
         if (d.wm == 8 && wgs >= w8_below) continue;          // 8-wave tiles only where one workgroup per CU is all there is
+        static const int allow_4x2 = getenv("MIDD_TILE_4X2") ? atoi(getenv("MIDD_TILE_4X2")) : 0;
+        if (d.wm == 4 && d.wn == 2 && !allow_4x2) continue;
         const long share = (pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm) + (d.wm == 8 ? 4 : 0);
         const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }

@@ -29,7 +29,6 @@ struct ConvArgs {
     float* out;             // NHWC [B][OH][OW][Cout]
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     const float* zeros;     // (unused) 64 zero floats
-    int debug;              // timing experiments only (MIDD_DEBUG): 1 no weight DMA, 2 no activation DMA, 4 no MFMA, 8 no step barrier, 16 no transform
     // optional fused GroupNorm statistics of the OUTPUT: per (sample, row, channel) partial sum and
     // sum of squares, layout [B][stat_rows][2][Cout]; row = tile*WM + wave_m (see conv_stat_rows)
     float* stat_partial;
