@@ -37,9 +37,9 @@ PEAK_HBM = 8.0e12
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes
-    (profiles/r01b_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
+    (profiles/r01c_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
     corrections applied as MI355X_MICROARCH.md prescribes), or None."""
-    path = os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"].get(kernel_name)
@@ -200,8 +200,9 @@ def main():
             x_gpu = model.run_sampler(one, steps, den.beta, den.alpha, den.alpha_hat, clamp_eps=True)
             result["parity_max_abs_err_vs_oracle"] = float((x_gpu.cpu() - x_cpu).abs().max())
             result["speedup_vs_cpu_baseline"] = value / base["value"]
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0's roofline leg runs after the timed region; leave together
         dist.destroy_process_group()
 
 

@@ -987,7 +987,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
     }
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, s));   // x = noisy_img.clone()
     const int parts = split_parts(B);
-    if (parts > 1 && !plan->profiling && n_iters > 0) {
+    if (parts > 1 && n_iters > 0) {
         // Images are independent: the batch runs as `parts` sub-batches on as many streams, each started
         // 1/parts of a forward after the previous one, so that one part's latency-bound low-resolution
         // layers (one workgroup per CU at B=8) share the chip with another part's HBM-bound high-resolution
