@@ -15,6 +15,7 @@
 // Every fp32 operand x is used as x*2^s = hi + lo (fp16 each, exact power-of-two prescale):
 // q,k,v: s = 4; p in [0,1]: s = 10; hi.hi + hi.lo + lo.hi reproduces the fp32 product to ~2^-21.
 #include "midd_internal.h"
+#include <cstdlib>
 
 namespace midd {
 
@@ -80,8 +81,8 @@ void attention_prep_kernel(const float* __restrict__ qkv, _Float16* __restrict__
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(256)
+template <int D, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64)
 void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vp,
                             float* __restrict__ out, int N, int Npad, int C, float qscale) {
     constexpr int DC = D / 32;                 // 32-wide k chunks of the head dimension (QK^T)
@@ -96,7 +97,8 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    constexpr int NT_ = NWAVES * 64;           // threads per workgroup; NWAVES*16 queries per workgroup
+    const int q0 = blockIdx.x * (NWAVES * 16) + wave * 16;
     const int C3 = 3 * C;
     const float* base = qkv + (size_t)b * N * C3;
     const int qcol = head * D;
@@ -132,13 +134,13 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
 
     // register-staged software pipeline: tile t+1 is fetched (16-byte copies of the pre-split
     // images) while tile t is being multiplied; it is written to LDS after the barrier that ends t.
-    constexpr int KSL = (A16_KT * (D / 8) + 255) / 256;        // 16-byte K slots per thread and plane
-    constexpr int VSL = (D * (A16_KT / 8) + 255) / 256;
+    constexpr int KSL = (A16_KT * (D / 8) + NT_ - 1) / NT_;    // 16-byte K slots per thread and plane
+    constexpr int VSL = (D * (A16_KT / 8) + NT_ - 1) / NT_;
     half8 pkh[KSL], pkl[KSL], pvh[VSL], pvl[VSL];
     auto fetch = [&](int kt0) {
 #pragma unroll
         for (int i = 0; i < KSL; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT_;
             const int key = idx / (D / 8), d8 = idx - key * (D / 8);
             half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
             if (idx < A16_KT * (D / 8) && kt0 + key < N) {
@@ -149,7 +151,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
         }
 #pragma unroll
         for (int i = 0; i < VSL; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT_;
             const int d = idx / (A16_KT / 8), k8 = idx - d * (A16_KT / 8);
             half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
             if (idx < D * (A16_KT / 8)) {
@@ -162,7 +164,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     auto commit = [&]() {
 #pragma unroll
         for (int i = 0; i < KSL; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT_;
             const int key = idx / (D / 8), d8 = idx - key * (D / 8);
             if (idx < A16_KT * (D / 8)) {
                 *reinterpret_cast<half8*>(&Kh[key * KLD + d8 * 8]) = pkh[i];
@@ -171,7 +173,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
         }
 #pragma unroll
         for (int i = 0; i < VSL; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT_;
             const int d = idx / (A16_KT / 8), k8 = idx - d * (A16_KT / 8);
             if (idx < D * (A16_KT / 8)) {
                 *reinterpret_cast<half8*>(&Vh[d * VLD + k8 * 8]) = pvh[i];
@@ -282,13 +284,21 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
     hipLaunchKernelGGL(attention_prep_kernel, dim3(Npad / 64, heads, B), dim3(256), 0, s, qkv, Kp, Vp, N, Npad, C, D, heads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    dim3 grid((N + 63) / 64, heads, B), block(256);
+    // 64 queries per workgroup, or 32 when that leaves CUs idle (split half-batches at B = 8: 128 workgroups)
+    static const int small_ok = getenv("MIDD_ATT_SMALL") ? atoi(getenv("MIDD_ATT_SMALL")) : 0;   // measured: 64-query workgroups win even at 128 workgroups
+    const bool small = small_ok && (long)((N + 63) / 64) * heads * B < 256;
+#define MIDD_ATT(DD)                                                                                              \
+    if (small) hipLaunchKernelGGL((attention_f16x3_kernel<DD, 2>), dim3((N + 31) / 32, heads, B), dim3(128), 0, s, \
+                                  qkv, Kp, Vp, out, N, Npad, C, qscale);                                          \
+    else hipLaunchKernelGGL((attention_f16x3_kernel<DD, 4>), dim3((N + 63) / 64, heads, B), dim3(256), 0, s,      \
+                            qkv, Kp, Vp, out, N, Npad, C, qscale);
     switch (D) {
-        case 32:  hipLaunchKernelGGL(attention_f16x3_kernel<32>, grid, block, 0, s, qkv, Kp, Vp, out, N, Npad, C, qscale); break;
-        case 64:  hipLaunchKernelGGL(attention_f16x3_kernel<64>, grid, block, 0, s, qkv, Kp, Vp, out, N, Npad, C, qscale); break;
-        case 96:  hipLaunchKernelGGL(attention_f16x3_kernel<96>, grid, block, 0, s, qkv, Kp, Vp, out, N, Npad, C, qscale); break;
-        case 128: hipLaunchKernelGGL(attention_f16x3_kernel<128>, grid, block, 0, s, qkv, Kp, Vp, out, N, Npad, C, qscale); break;
+        case 32:  MIDD_ATT(32) break;
+        case 64:  MIDD_ATT(64) break;
+        case 96:  MIDD_ATT(96) break;
+        case 128: MIDD_ATT(128) break;
     }
+#undef MIDD_ATT
     return hipGetLastError();
 }
 

@@ -851,7 +851,9 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             }
         }
         if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
-        if (mid_event && (size_t)(&o - g->ops.data()) == g->ops.size() / mid_div) (void)hipEventRecord(mid_event, s);
+        static const int phase_pct = getenv("MIDD_PHASE_PCT") ? atoi(getenv("MIDD_PHASE_PCT")) : 0;
+        const size_t mid_at = phase_pct ? g->ops.size() * phase_pct / 100 : g->ops.size() / mid_div;
+        if (mid_event && (size_t)(&o - g->ops.data()) == mid_at) (void)hipEventRecord(mid_event, s);
         if (p->profiling) {
             (void)hipEventRecord(ev_b, s);
             mi_plan::Span sp; sp.a = ev_a; sp.b = ev_b;

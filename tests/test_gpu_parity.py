@@ -207,6 +207,28 @@ def test_full_size_properties(full_model):
     assert float(a.min()) >= 0 and float(a.max()) <= 1 and torch.isfinite(a).all()
 
 
+@pytest.mark.parametrize("variant", ["ddim", "cddpm"])
+def test_split_run_matches_oracle(variant):
+    """B >= 4 runs as two half-batches on two streams (mi_denoise): same results as the oracle,
+    including the per-iteration noise slices of the stochastic variant."""
+    cfg = UNetConfig(variant=variant, **SMALL)
+    sd = make_state_dict(cfg, seed=9, perturb_norm=True)
+    model = _model(SMALL, sd, variant)
+    B, H, W, S = 6, 40, 32, 5
+    noisy = torch.from_numpy(synthetic_xray(B, H, W, seed=400))
+    steps = timestep_list(50, S)
+    kw, okw = {}, {}
+    if variant == "cddpm":
+        g = np.random.Generator(np.random.Philox(key=5))
+        noise = torch.from_numpy(np.stack([0.5 * g.standard_normal((B, 1, H, W), dtype=np.float32) for _ in steps]))
+        kw["step_noise"] = noise.cuda()
+        okw["step_noise"] = list(noise)
+    out = DiffusionDenoiser(model, noise_steps=50).denoise(noisy.cuda(), inference_steps=S, **kw)
+    want = orc.denoise(orc.to_torch(sd), topology(cfg), noisy, 50, S, **okw)
+    assert _maxdiff(out.cpu().numpy(), want.numpy()) < TOL_FINAL
+    assert _maxdiff(out.cpu().numpy(), want.numpy()) < 5e-5
+
+
 # ------------------------------------------------------------------------------ errors
 def test_error_behaviour():
     cfg = UNetConfig(**SMALL)
