@@ -107,7 +107,9 @@ struct Conv16Geom {
 #ifndef MIDD_RING_MAX
 #define MIDD_RING_MAX 6
 #endif
-    static constexpr int LDS_TARGET = MIDD_LDS_TARGET_KB * 1024;    // 52 KB: three workgroups per CU
+    // 52 KB: three workgroups per CU; the wide (NT = 6) tile trades one resident workgroup for twice the
+    // MFMA work per staged activation, per barrier and per DMA group
+    static constexpr int LDS_TARGET = (NT > 3 ? 80 : MIDD_LDS_TARGET_KB) * 1024;
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
@@ -120,7 +122,7 @@ template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 #endif
 // the register budget is capped so that as many workgroups as the LDS target allows are resident
 // (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? MIDD_CONV16_WAVES_PER_SIMD : 1)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (NT > 3 ? 2 : MIDD_CONV16_WAVES_PER_SIMD) : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
@@ -527,7 +529,7 @@ int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, i
 
 #define MIDD_CONV16_TILES(X)                  \
     /*  tw  mt nt wm wn */                    \
-    X(16, 4, 3, 4, 1) X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) X(16, 1, 3, 8, 1) \
+    X(16, 4, 3, 4, 1) X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) X(16, 1, 3, 8, 1) X(16, 2, 6, 4, 1) \
     X(16, 2, 3, 4, 2) X(16, 4, 3, 2, 2) X(16, 2, 3, 2, 2) X(16, 1, 3, 2, 2) X(8, 1, 3, 1, 2) \
     X(16, 4, 3, 1, 3) X(16, 2, 3, 1, 3) X(8, 1, 3, 1, 3)                   \
     X(16, 4, 3, 1, 4) X(16, 2, 3, 1, 4) X(8, 2, 3, 1, 4) X(8, 1, 3, 1, 4)  \
@@ -551,7 +553,7 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
     const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + 2 * 512 * 4;
-    long ring = (MIDD_LDS_TARGET_KB * 1024 - fixed) / (wpieces * 1024);
+    long ring = ((d.nt > 3 ? 80 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
@@ -567,13 +569,17 @@ bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvT
     static const int max_mt = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 2;   // tuning knobs (measured: 2 beats 4)
     static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 256;
     static const int pix_first = getenv("MIDD_PIX_FIRST") ? atoi(getenv("MIDD_PIX_FIRST")) : 1;
+    static const int wide_ok = getenv("MIDD_TILE_NT6") ? atoi(getenv("MIDD_TILE_NT6")) : 0;
     for (const Tile16& d : kTiles16) {
-        if (d.nt != nt || nn % d.wn) continue;
+        const bool wide = (d.nt == 2 * nt) && wide_ok && (Cout % (16 * d.nt) == 0);
+        if (d.nt != nt && !wide) continue;
+        const int nn_d = Cout / (16 * d.nt);
+        if (nn_d % d.wn) continue;
         if (d.mt > max_mt) continue;
         if (!tile16_fits(d, ks, stride)) continue;
         const int bm = d.wm * d.mt * 16, th = bm / d.tw;
         const long tiles = (long)((OW + d.tw - 1) / d.tw) * ((OH + th - 1) / th);
-        const long wgs = (long)B * tiles * (nn / d.wn);
+        const long wgs = (long)B * tiles * (nn_d / d.wn);
         const long covered = tiles * d.tw * th;
         const bool wasteful = covered * 4 > (long)OH * OW * 5;
         // enough workgroups first; then the pixels one weight fetch is shared over (the weight stream
@@ -582,7 +588,7 @@ bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvT
         if (d.wm == 8 && wgs >= w8_below) continue;          // 8-wave tiles only where one workgroup per CU is all there is
         static const int allow_4x2 = getenv("MIDD_TILE_4X2") ? atoi(getenv("MIDD_TILE_4X2")) : 0;
         if (d.wm == 4 && d.wn == 2 && !allow_4x2) continue;
-        const long share = (pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm) + (d.wm == 8 ? 4 : 0);
+        const long share = (pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm) + (d.wm == 8 ? 4 : 0) + (wide ? 2 : 0);
         const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }
     }
