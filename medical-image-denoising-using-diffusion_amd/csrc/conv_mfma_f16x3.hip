@@ -29,6 +29,12 @@
 #include "midd_internal.h"
 #include <cstdlib>
 #include <type_traits>
+#ifdef MIDD_CONV_TIMING
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#endif
 
 namespace midd {
 
@@ -115,6 +121,25 @@ struct Conv16Geom {
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
     static_assert(BM % TW == 0, "tile");
 };
+
+// Diagnostic build only (-DMIDD_CONV_TIMING, tools/conv_timing.py): s_memtime stamps of wave 0 of every
+// workgroup, summed per launch shape.  Shares, not run times: the stamps drain the LDS queue.
+#ifdef MIDD_CONV_TIMING
+enum { TS_WAIT, TS_ISSUE, TS_MFMA, TS_CHUNK_WAIT, TS_TRANSFORM, TS_EPILOGUE, TS_PROLOGUE, TS_FIRSTWAIT, TS_TOTAL, TS_REAL, TS_WGS, TS_N };
+__device__ unsigned long long g_conv_timing[64][TS_N];
+__device__ __forceinline__ unsigned long long ts_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define TS_DECL bool ts_after_epi = false; unsigned long long ts_acc[TS_N] = {}; unsigned long long ts_last = ts_stamp(); const unsigned long long ts_t0 = ts_last; const unsigned long long ts_r0 = __builtin_amdgcn_s_memrealtime();
+#define TS(k) { const unsigned long long t_ = ts_stamp(); ts_acc[k] += t_ - ts_last; ts_last = t_; }
+#else
+#define TS_DECL
+#define TS(k)
+#endif
 
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 #ifndef MIDD_CONV16_WAVES_PER_SIMD
@@ -288,6 +313,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // min(nsteps-1, D) weight groups issued after it.  The slot refilled after the barrier of step
     // s, (s+D)%RING == (s-1)%RING, was last read before that barrier by every wave.
     constexpr int D = RING - 1;
+    const int ntile0 = ntile_wg + wn * NT;
+    TS_DECL
     issue_a(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
@@ -305,6 +332,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         asm volatile("" ::: "memory");
     }
 
+    TS(TS_PROLOGUE)
     int rd_slot = 0;
     half8 xh[MT], xl[MT];
     auto load_x = [&](const int (&xo)[MT]) {
@@ -360,14 +388,18 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+#ifdef MIDD_CONV_TIMING
+        if (ts_after_epi) { TS(TS_FIRSTWAIT) ts_after_epi = false; } else { TS(TS_WAIT) }
+#endif
         if (!early) load_x(xo);
         issue_w();
         if (first_with_more) issue_a(next_chunk);  // each thread already consumed its own raw slots
+        TS(TS_ISSUE)
         mfma_step();
+        TS(TS_MFMA)
     };
 
     // ---- epilogue (per tile) ------------------------------------------------------------------
-    const int ntile0 = ntile_wg + wn * NT;
     f32x4 add_v[NT];                                      // bias (+ time embedding), loaded once per workgroup
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
@@ -467,12 +499,18 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 if (nsteps - 1 >= D) wait_vm_and_barrier<D * PPW>();
                 else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
                 else wait_vm_and_barrier<0>();
+                TS(TS_CHUNK_WAIT)
                 if (!more_in_tile) {                    // tile finished: store it, move to the next one
                     epilogue();
                     trem = next_tile;
                     oy0 = (trem / a.tiles_x) * TH; ox0 = (trem % a.tiles_x) * TW;
+                    TS(TS_EPILOGUE)
+#ifdef MIDD_CONV_TIMING
+                    ts_after_epi = true;
+#endif
                 }
                 transform(next_chunk);
+                TS(TS_TRANSFORM)
                 if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
@@ -485,12 +523,49 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         if (!has_next_tile) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight refills issued past the last step
+    TS(TS_CHUNK_WAIT)
     epilogue();
     publish_stats();
+    TS(TS_EPILOGUE)
+#ifdef MIDD_CONV_TIMING
+    if (tid == 0) {
+        ts_acc[TS_TOTAL] = ts_last - ts_t0;
+        ts_acc[TS_REAL] = __builtin_amdgcn_s_memrealtime() - ts_r0;
+        ts_acc[TS_WGS] = 1;
+        for (int k = 0; k < TS_N; ++k) atomicAdd(&g_conv_timing[a.dbg_slot][k], ts_acc[k]);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------ dispatch
 static int conv16_wgs_per_img(int tiles, int B, int ny);
+#ifdef MIDD_CONV_TIMING
+static std::vector<std::string> g_timing_names;
+static int conv_timing_slot(int ks, int st, int tw, int mt, int nt, int wm, int wn, int oh, int cin, int cout, int B, int ring, int wgs) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "k%d s%d tile(%d,%d,%d,%d,%d) ring%d out%d^2 %d->%d B%d wgs%d", ks, st, tw, mt, nt, wm, wn, ring, oh, cin, cout, B, wgs);
+    for (size_t i = 0; i < g_timing_names.size(); ++i) if (g_timing_names[i] == buf) return (int)i;
+    if (g_timing_names.size() >= 63) return 63;
+    g_timing_names.push_back(buf);
+    return (int)g_timing_names.size() - 1;
+}
+extern "C" __attribute__((visibility("default"))) void mi_debug_conv_timing_dump(void) {
+    static unsigned long long h[64][TS_N];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_timing), sizeof h);
+    static const char* names[] = {"wait+bar", "dma-issue", "frag+mfma", "chunk-wait", "transform", "epilogue", "prologue", "wait-after-epi"};
+    for (size_t i = 0; i < g_timing_names.size(); ++i) {
+        const double tot = (double)h[i][TS_TOTAL], wgs = (double)h[i][TS_WGS];
+        if (wgs == 0) continue;
+        printf("%-70s cyc/wg %9.0f clk %.2f GHz |", g_timing_names[i].c_str(), tot / wgs, tot / (double)h[i][TS_REAL] * 0.1);
+        for (int k = 0; k < 8; ++k) printf(" %s %4.1f%%", names[k], 100.0 * (double)h[i][k] / tot);
+        printf("\n");
+    }
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), h, sizeof h);
+    fflush(stdout);
+}
+#endif
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
@@ -500,6 +575,9 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     const int ny = a.Cout / (WN * NT * 16);
     a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny);
     dim3 grid(a.B * a.wgs_per_img, ny);
+#ifdef MIDD_CONV_TIMING
+    a.dbg_slot = conv_timing_slot(KS, STRIDE, TW, MT, NT, WM, WN, a.OH, a.C0 + a.C1, a.Cout, a.B, G::RING, (int)grid.x * (int)grid.y);
+#endif
     if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
         if (a.C0 + a.C1 > G::MAX_CIN) return hipErrorInvalidValue;
         if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets

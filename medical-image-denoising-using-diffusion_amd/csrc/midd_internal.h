@@ -35,6 +35,9 @@ struct ConvArgs {
     int stat_rows;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
+#ifdef MIDD_CONV_TIMING
+    int dbg_slot;           // diagnostic build: row of g_conv_timing
+#endif
 };
 
 struct ConvTile {           // which template instance to launch

@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmidd.so")
+# MIDD_LIBRARY: development only (A/B runs of two builds on one box); there is no other implementation behind it
+LIB_PATH = os.environ.get("MIDD_LIBRARY") or os.path.join(_HERE, "libmidd.so")
 
 MI_MAX_LEVELS = 8
 MI_VARIANT = {"ddim": 0, "cddpm": 1}
