@@ -102,8 +102,15 @@ struct Conv16Geom {
     static constexpr int WPIECES = WN * NT * 2;                     // 1 KiB weight pieces per step
     static constexpr int PPW = (WPIECES + NW - 1) / NW;             // pieces per wave and step (duplicates pad)
     static constexpr int WSLICE = WPIECES * 1024;
-    static constexpr int MAX_CIN = 512;
-    static constexpr int FIXED_BYTES = RAW_BYTES + IMG_BYTES + 2 * MAX_CIN * 4;
+    // epilogue state kept in LDS instead of registers (the K loop is register-bound): GroupNorm partial
+    // sums of the output, one row [2][NT*16] per wave, and the bias (+ time embedding) vector of the workgroup
+    static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
+    static constexpr int ADD_FLOATS = WN * NT * 16;
+    static constexpr int EPI_BYTES = (STAT_FLOATS + ADD_FLOATS) * 4;
+    // GroupNorm scale/shift of the input, [2][Cin] floats, sized at launch (dynamic LDS); the ring is
+    // dimensioned for up to NOMINAL_CIN input channels (more still runs, possibly one workgroup per CU fewer)
+    static constexpr int NOMINAL_CIN = 384;
+    static constexpr int FIXED_BYTES = RAW_BYTES + IMG_BYTES + EPI_BYTES + 2 * NOMINAL_CIN * 4;
     // weight steps resident in LDS (prefetch distance RING-1): L2->LDS latency is ~1-2k cycles under
     // load, a step is only 150-600 MFMA cycles, so take as many slots as fit in half the LDS (two
     // workgroups per CU), between 2 and 6.
@@ -118,7 +125,8 @@ struct Conv16Geom {
     static constexpr int LDS_TARGET = (NT > 3 ? 80 : MIDD_LDS_TARGET_KB) * 1024;
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
-    static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;
+    static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;                 // at NOMINAL_CIN
+    static constexpr int lds_bytes(int cin) { return LDS_BYTES + 2 * (cin - NOMINAL_CIN) * 4; }
     static_assert(BM % TW == 0, "tile");
 };
 
@@ -157,11 +165,13 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     constexpr int HSTEPS = (TAPS + 1) / 2;
     constexpr int PPW = G::PPW, WSLICE = G::WSLICE, RING = G::RING;
 
-    __shared__ __attribute__((aligned(16))) char lds[G::LDS_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char lds[];             // G::lds_bytes(Cin)
     char* const raw = lds;
     char* const img = lds + G::RAW_BYTES;
     char* const wring = img + G::IMG_BYTES;
-    float* const gnp = reinterpret_cast<float*>(wring + RING * WSLICE);     // [2][MAX_CIN] scale, shift
+    float* const stat_lds = reinterpret_cast<float*>(wring + RING * WSLICE);   // [wave][2][NT*16]
+    float* const add_lds = stat_lds + G::STAT_FLOATS;                           // [WN*NT*16]
+    float* const gnp = add_lds + G::ADD_FLOATS;                                 // [2][Cin] scale, shift
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -254,7 +264,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         f32x4 sc = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
         if (a.prologue != PRO_RAW) {
             sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
-            sh = *reinterpret_cast<const f32x4*>(gnp + G::MAX_CIN + ch) * ACT_PRESCALE;
+            sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch) * ACT_PRESCALE;
         }
         char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
 #pragma unroll
@@ -321,7 +331,15 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     if (a.prologue != PRO_RAW) {
         for (int i = tid; i < Cin; i += NTHREADS) {
             gnp[i] = a.gn_scale[(size_t)b * Cin + i];
-            gnp[G::MAX_CIN + i] = a.gn_shift[(size_t)b * Cin + i];
+            gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i];
+        }
+    }
+    for (int i = tid; i < G::STAT_FLOATS; i += NTHREADS) stat_lds[i] = 0.f;
+    {
+        const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
+        for (int i = tid; i < G::ADD_FLOATS; i += NTHREADS) {
+            const int co = ntile_wg * 16 + i;
+            add_lds[i] = a.bias[co] + (a.temb != nullptr ? a.temb[(size_t)trow * a.temb_stride + co] : 0.f);
         }
     }
     wait_vm_and_barrier<0>();               // everything above has landed / is visible (once per launch)
@@ -400,26 +418,17 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     };
 
     // ---- epilogue (per tile) ------------------------------------------------------------------
-    f32x4 add_v[NT];                                      // bias (+ time embedding), loaded once per workgroup
-    {
-        const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (ntile0 + nt) * 16 + kq * 4;
-            add_v[nt] = *reinterpret_cast<const f32x4*>(a.bias + co);
-            if (a.temb != nullptr) add_v[nt] += *reinterpret_cast<const f32x4*>(a.temb + (size_t)trow * a.temb_stride + co);
-        }
-    }
     // GroupNorm partial sums of the output run across ALL tiles of this (persistent) workgroup and are
-    // published once at the end: one row per (workgroup, wave) instead of one per (tile, wave)
-    f32x4 ssum[NT], ssq[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // published once at the end: one row per (workgroup, wave) instead of one per (tile, wave).  Per tile the
+    // 16 pixel lanes are folded (fixed order -> deterministic) and lanes p16 == 0 add into the wave's LDS row.
+    float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
     auto epilogue = [&]() {
+        f32x4 tsum[NT], tsq[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+            tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int co = (ntile0 + nt) * 16 + kq * 4;
-            const f32x4 add = add_v[nt];
+            const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pp = (wm * MT + mt) * 16 + p16;
@@ -430,26 +439,34 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     f32x4 v = acc[mt][nt] * a.out_scale + add;
                     if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
                     *reinterpret_cast<f32x4*>(a.out + o) = v;
-                    ssum[nt] += v; ssq[nt] += v * v;
+                    tsum[nt] += v; tsq[nt] += v * v;
                 }
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
+        if (a.stat_partial != nullptr) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tsum[nt][e] = row16_sum(tsum[nt][e]); tsq[nt][e] = row16_sum(tsq[nt][e]); }
+                if (p16 == 0) {
+                    f32x4* ps = reinterpret_cast<f32x4*>(my_stat + nt * 16);
+                    f32x4* pq = reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16);
+                    *ps = *ps + tsum[nt];
+                    *pq = *pq + tsq[nt];
+                }
+            }
+        }
     };
     auto publish_stats = [&]() {
-        if (a.stat_partial == nullptr) return;
-        // fold the 16 pixel lanes (fixed order -> deterministic), lanes p16 == 0 publish 4 channels each
+        if (a.stat_partial == nullptr || p16 != 0) return;
         const int row = (blockIdx.x - b * a.wgs_per_img) * WM + wm;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
-            if (p16 == 0) {
-                const int co = (ntile0 + nt) * 16 + kq * 4;
-                float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
-                *reinterpret_cast<f32x4*>(pr) = ssum[nt];
-                *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
-            }
+            const int co = (ntile0 + nt) * 16 + kq * 4;
+            float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
+            *reinterpret_cast<f32x4*>(pr) = *reinterpret_cast<const f32x4*>(my_stat + nt * 16);
+            *reinterpret_cast<f32x4*>(pr + a.Cout) = *reinterpret_cast<const f32x4*>(my_stat + NT * 16 + nt * 16);
         }
     };
 
@@ -579,9 +596,19 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     a.dbg_slot = conv_timing_slot(KS, STRIDE, TW, MT, NT, WM, WN, a.OH, a.C0 + a.C1, a.Cout, a.B, G::RING, (int)grid.x * (int)grid.y);
 #endif
     if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
-        if (a.C0 + a.C1 > G::MAX_CIN) return hipErrorInvalidValue;
+        const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
+        if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+        if (lds_bytes > 64 * 1024) {
+            static int raised = 0;           // per instantiation
+            if (lds_bytes > raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                if (e != hipSuccess) return e;
+                raised = lds_bytes;
+            }
+        }
         if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets
-        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(G::NTHREADS), 0, s, a);
+        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(G::NTHREADS), lds_bytes, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;        // tile never picked (conv16_pick_tile), not instantiated
@@ -630,7 +657,7 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int cb = conv16_cb(ks);
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
-    const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + 2 * 512 * 4;
+    const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4;
     long ring = ((d.nt > 3 ? 80 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
