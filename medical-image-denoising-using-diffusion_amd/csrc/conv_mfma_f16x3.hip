@@ -122,7 +122,7 @@ struct Conv16Geom {
 #endif
     // 52 KB: three workgroups per CU; the wide (NT = 6) tile trades one resident workgroup for twice the
     // MFMA work per staged activation, per barrier and per DMA group
-    static constexpr int LDS_TARGET = (NT > 3 ? 80 : MIDD_LDS_TARGET_KB) * 1024;
+    static constexpr int LDS_TARGET = ((NT > 3 || MT > 2) ? 80 : MIDD_LDS_TARGET_KB) * 1024;
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;                 // at NOMINAL_CIN
@@ -155,7 +155,7 @@ template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 #endif
 // the register budget is capped so that as many workgroups as the LDS target allows are resident
 // (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? (NT > 3 ? 2 : MIDD_CONV16_WAVES_PER_SIMD) : 1)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? ((NT > 3 || MT > 2) ? 2 : MIDD_CONV16_WAVES_PER_SIMD) : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
@@ -658,20 +658,31 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
     const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4;
-    long ring = ((d.nt > 3 ? 80 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
+    long ring = (((d.nt > 3 || d.mt > 2) ? 80 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
 }
 
-bool conv16_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t) {
+bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t) {
     if (Cout % 16) return false;
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const int nn = Cout / (16 * nt);                      // cout slices of 16*nt; a workgroup takes wn of them
     const Tile16* best = nullptr;
     long best_score = -(1L << 60);
-    static const int max_mt = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 2;   // tuning knobs (measured: 2 beats 4)
+    // 16x16-pixel tiles (MT = 4, two workgroups per CU) halve the weight bytes streamed per MAC.  Measured (B=8,
+    // 256x256 input): -5..-12 % on the 3x3 convs whose tensors stay in the Infinity Cache and whose weight stream
+    // dominates (128x128 maps, >= 96 input channels); +15..35 % on the HBM-bound 256x256 maps (they need the third
+    // workgroup's loads in flight) and on maps too small to give every CU two such workgroups.
+    static const int max_mt_env = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 0;
+    const double moved_mb = 4.0 * B * ((double)OH * stride * OW * stride * Cin + (double)OH * OW * Cout) / 1048576.0;
+    const long wgs_mt4 = (long)B * ((OW + 15) / 16) * ((OH + 15) / 16) * (Cout / (16 * ((Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1)));
+    // With the batch split over two streams (the default) the selective rule is a net loss (-1.5..-3 %; +0.4 %
+    // unsplit), so it is opt-in.
+    static const int big_rule = getenv("MIDD_TILE_BIG") ? atoi(getenv("MIDD_TILE_BIG")) : 0;
+    const bool big_ok = big_rule && ks == 3 && stride == 1 && Cin >= 96 && moved_mb <= 96.0 && wgs_mt4 >= 512;
+    const int max_mt = max_mt_env ? max_mt_env : (big_ok ? 4 : 2);
     static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 256;
     static const int pix_first = getenv("MIDD_PIX_FIRST") ? atoi(getenv("MIDD_PIX_FIRST")) : 1;
     static const int wide_ok = getenv("MIDD_TILE_NT6") ? atoi(getenv("MIDD_TILE_NT6")) : 0;

@@ -555,7 +555,7 @@ struct Builder {
         if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
         if (resid) { o.resid = *resid; o.has_resid = true; }
         const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
-                            ? conv16_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
+                            ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
                             : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
         if (want_stats) {
