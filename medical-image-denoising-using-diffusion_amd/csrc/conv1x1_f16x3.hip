@@ -1,0 +1,271 @@
+// 1x1 convolution (res_conv, attention qkv / proj: DDIMModel.py:52,90-91 / cddpmModels.py:55,104-105) in
+// f16x3 arithmetic (see conv_mfma_f16x3.hip for the number format), as a GEMM  out[p][co] = sum_ci act(x[p][ci]) * W[co][ci]
+// over the flattened pixels of a sample.
+//
+// A 1x1 conv has no halo and no taps, so the general kernel's machinery (raw staging in LDS, transform pass,
+// chunk barriers, weight ring) is pure latency here: with one K-step per chunk it serialises a DMA round trip
+// per 32 channels.  This kernel instead
+//   * loads each lane's B operand straight from global memory: lane (pixel p16, k-quarter kq) of a 16x16x32
+//     MFMA needs channels kq*8 .. kq*8+7 of its pixel = 32 contiguous bytes in NHWC; GroupNorm-apply / SiLU /
+//     2^s prescale / hi-lo split happen in registers (each element once per workgroup, as before);
+//   * keeps ALL weights of the workgroup's 16*NT output channels in LDS (Cin * NT * 64 B: 36 KB at Cin = 192),
+//     fetched once by LDS-DMA and reused for every pixel tile the persistent workgroup walks;
+//   * has no barrier in the K loop; the activation loads run two K-steps ahead in registers, across tile borders.
+// Epilogue and contract are those of conv_mfma_f16x3.hip (bias / time embedding / residual, GroupNorm partial
+// sums of the output per (workgroup, wave) row).  Weight pack: pack_conv_f16x3 (midd_api.hip), 32 channels per step.
+#include "f16x3_common.h"
+#include <cstdlib>
+
+namespace midd {
+
+template <int MT, int NT>
+struct Conv1Geom {
+    static constexpr int NW = 4, NTHREADS = 256;
+    static constexpr int BM = NW * MT * 16;                  // pixels per tile
+    static constexpr int WSTEP = NT * 2048;                  // bytes of one K-step's weights (hi + lo, NT cout tiles)
+    static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
+    static constexpr int ADD_FLOATS = NT * 16;
+    static int lds_bytes(int cin) { return ((cin + 31) / 32) * WSTEP + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4; }
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 3)
+void conv1x1_f16x3_kernel(const ConvArgs a) {
+    using G = Conv1Geom<MT, NT>;
+    constexpr int BM = G::BM, WSTEP = G::WSTEP;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15;
+    const int kq = lane >> 4;
+
+    const int Cin = a.C0 + a.C1;
+    const int nsteps = (Cin + 31) >> 5;
+    const int HW = a.OH * a.OW;
+    const int tiles = a.tiles_x;                              // ceil(HW / BM)
+    const int b = blockIdx.x / a.wgs_per_img;
+    const int first_tile = blockIdx.x - b * a.wgs_per_img;    // then first_tile + wgs_per_img, ...
+    const int my_tiles = (tiles - first_tile + a.wgs_per_img - 1) / a.wgs_per_img;
+    const int ntiles_total = a.Cout >> 4;
+    const int ntile_wg = blockIdx.y * NT;
+
+    char* const wl = lds;                                                        // [step][NT][hi|lo][lane] x 16 B
+    float* const stat_lds = reinterpret_cast<float*>(wl + nsteps * WSTEP);       // [wave][2][NT*16]
+    float* const add_lds = stat_lds + G::STAT_FLOATS;                            // [NT*16]
+    float* const gnp = add_lds + G::ADD_FLOATS;                                  // [2][Cin] scale, shift
+
+    // ---- activation operand: registers, two K-steps ahead -------------------------------------
+    // sequence s = 0 .. my_tiles*nsteps-1 walks (tile, step); each lane loads 8 channels of MT pixels per s
+    const size_t img0 = (size_t)b * HW;
+    auto load_a = [&](int tile, int step, f32x4 (&r)[MT][2]) {
+        int ch = step * 32 + kq * 8;
+        if (ch >= Cin) ch = Cin - 8;                          // trailing half step: valid dummy, zeroed in transform
+        const float* src; int cs;
+        if (ch < a.C0) { src = a.src0 + ch; cs = a.C0; } else { src = a.src1 + (ch - a.C0); cs = a.C1; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = min(tile * BM + (wave * MT + mt) * 16 + p16, HW - 1);
+            const float* q = src + (img0 + p) * cs;
+            r[mt][0] = *reinterpret_cast<const f32x4*>(q);
+            r[mt][1] = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+    };
+    f32x4 ra[2][MT][2];
+    const int total = my_tiles * nsteps;
+    int pf_tile = first_tile, pf_step = 0;                    // next (tile, step) to request
+    auto advance = [&](int& tile, int& step) { if (++step == nsteps) { step = 0; tile += a.wgs_per_img; } };
+    load_a(pf_tile, pf_step, ra[0]); advance(pf_tile, pf_step);
+    if (total > 1) { load_a(pf_tile, pf_step, ra[1]); advance(pf_tile, pf_step); }
+
+    // ---- weights: the whole K extent of this workgroup's couts, once ---------------------------
+    {
+        const char* wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048 + lane * 16;
+        const size_t wstep_bytes = (size_t)ntiles_total * 2048;
+        const int pieces = nsteps * NT * 2;                   // 1 KiB each
+        for (int piece = wave; piece < pieces; piece += G::NW) {
+            const int step = piece / (NT * 2), r = piece - step * (NT * 2);
+            dma16(wbase + step * wstep_bytes + r * 1024, wl + piece * 1024);
+        }
+    }
+    if (a.prologue != PRO_RAW) {
+        for (int i = tid; i < Cin; i += G::NTHREADS) {
+            gnp[i] = a.gn_scale[(size_t)b * Cin + i] * ACT_PRESCALE;     // the prescale is folded into the affine (exact)
+            gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i] * ACT_PRESCALE;
+        }
+    }
+    for (int i = tid; i < G::STAT_FLOATS; i += G::NTHREADS) stat_lds[i] = 0.f;
+    {
+        const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
+        for (int i = tid; i < G::ADD_FLOATS; i += G::NTHREADS) {
+            const int co = ntile_wg * 16 + i;
+            add_lds[i] = a.bias[co] + (a.temb != nullptr ? a.temb[(size_t)trow * a.temb_stride + co] : 0.f);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntile0 = ntile_wg;
+    float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+    auto epilogue = [&](int tile) {
+        f32x4 tsum[NT], tsq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int co = (ntile0 + nt) * 16 + kq * 4;
+            const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = tile * BM + (wave * MT + mt) * 16 + p16;
+                if (p < HW) {
+                    const size_t o = (img0 + p) * a.Cout + co;
+                    f32x4 v = acc[mt][nt] * a.out_scale + add;
+                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+                    *reinterpret_cast<f32x4*>(a.out + o) = v;
+                    tsum[nt] += v; tsq[nt] += v * v;
+                }
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (a.stat_partial != nullptr) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tsum[nt][e] = row16_sum(tsum[nt][e]); tsq[nt][e] = row16_sum(tsq[nt][e]); }
+                if (p16 == 0) {
+                    f32x4* ps = reinterpret_cast<f32x4*>(my_stat + nt * 16);
+                    f32x4* pq = reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16);
+                    *ps = *ps + tsum[nt];
+                    *pq = *pq + tsq[nt];
+                }
+            }
+        }
+    };
+
+    // ---- K loop: transform (registers) -> request the load two steps ahead -> MFMAs --------------
+    int c_tile = first_tile, c_step = 0;
+    auto compute = [&](f32x4 (&r)[MT][2], bool more) {
+        const int ch = c_step * 32 + kq * 8;
+        const bool valid = ch < Cin;
+        f32x4 sc0 = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sc1 = sc0;
+        f32x4 sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
+        if (a.prologue != PRO_RAW && valid) {
+            sc0 = *reinterpret_cast<const f32x4*>(gnp + ch);       sc1 = *reinterpret_cast<const f32x4*>(gnp + ch + 4);
+            sh0 = *reinterpret_cast<const f32x4*>(gnp + Cin + ch); sh1 = *reinterpret_cast<const f32x4*>(gnp + Cin + ch + 4);
+        }
+        half8 xh[MT], xl[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v0 = r[mt][0] * sc0 + sh0, v1 = r[mt][1] * sc1 + sh1;
+            if (a.prologue == PRO_GN_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {          // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
+                    v0[e] = v0[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v0[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+                    v1[e] = v1[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v1[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+                }
+            }
+            if (!valid) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }     // channels past Cin meet zero weights; keep them finite
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h0 = (_Float16)v0[e], h1 = (_Float16)v1[e];
+                xh[mt][e] = h0;     xl[mt][e] = (_Float16)(v0[e] - (float)h0);
+                xh[mt][4 + e] = h1; xl[mt][4 + e] = (_Float16)(v1[e] - (float)h1);
+            }
+        }
+        if (more) { load_a(pf_tile, pf_step, r); advance(pf_tile, pf_step); }   // r is consumed: refill it for s + 2
+        const char* wslot = wl + c_step * WSTEP + lane * 16;
+        half8 wh[NT], wlo[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
+            wlo[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+        if (c_step == nsteps - 1) epilogue(c_tile);
+        advance(c_tile, c_step);
+    };
+    for (int s = 0; s < total; s += 2) {
+        compute(ra[0], s + 2 < total);
+        if (s + 1 < total) compute(ra[1], s + 3 < total);
+    }
+
+    // ---- publish the GroupNorm partial sums: one row per (workgroup, wave) ---------------------------
+    if (a.stat_partial != nullptr && p16 == 0) {
+        const int row = first_tile * G::NW + wave;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = (ntile0 + nt) * 16 + kq * 4;
+            float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
+            *reinterpret_cast<f32x4*>(pr) = *reinterpret_cast<const f32x4*>(my_stat + nt * 16);
+            *reinterpret_cast<f32x4*>(pr + a.Cout) = *reinterpret_cast<const f32x4*>(my_stat + NT * 16 + nt * 16);
+        }
+    }
+}
+
+template <int MT, int NT>
+static hipError_t launch1(const ConvArgs& a0, hipStream_t s) {
+    using G = Conv1Geom<MT, NT>;
+    ConvArgs a = a0;
+    const int HW = a.OH * a.OW;
+    a.tiles_x = (HW + G::BM - 1) / G::BM;
+    a.tiles_y = 1;
+    const int ny = a.Cout / (NT * 16);
+    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x, a.B, ny);
+    const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (lds_bytes > 64 * 1024) {
+        static int raised = 0;               // per instantiation
+        if (lds_bytes > raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f16x3_kernel<MT, NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+            raised = lds_bytes;
+        }
+    }
+    hipLaunchKernelGGL((conv1x1_f16x3_kernel<MT, NT>), dim3(a.B * a.wgs_per_img, ny), dim3(G::NTHREADS), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+// tile.tw == 0 marks the flattened-pixel 1x1 kernel (tile = 64*mt pixels x 16*nt couts, 4 waves)
+bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t) {
+    static const int enabled = getenv("MIDD_CONV1X1_DIRECT") ? atoi(getenv("MIDD_CONV1X1_DIRECT")) : 1;
+    if (!enabled || Cout % 16 || Cin % 16) return false;
+    const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
+    const long wgs2 = (long)B * ((OH * OW + 127) / 128) * (Cout / (16 * nt));
+    const int mt = wgs2 >= 512 ? 2 : 1;                      // small maps: 64-pixel tiles, twice the workgroups
+    if (((Cin + 31) / 32) * nt * 2048 + 8 * Cin + 4096 > 150 * 1024) return false;   // all weights must fit in LDS
+    *t = ConvTile{1, 1, 0, mt, nt, 4, 1};
+    return true;
+}
+
+hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
+    if (a.C0 % 8 || a.C1 % 8) return hipErrorInvalidValue;  // an 8-channel lane group must not straddle the concat seam
+#define X(mt_, nt_) if (t.mt == mt_ && t.nt == nt_) return launch1<mt_, nt_>(a, s);
+    X(2, 3) X(1, 3) X(2, 2) X(1, 2) X(2, 1) X(1, 1)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace midd

@@ -26,7 +26,7 @@
 //     2 x 512 contiguous bytes, conflict-free).
 // K walk: 32 input channels (two 16-channel blocks) per step and tap; a trailing single block
 // (Cin = 48, 144) pairs two TAPS per step instead.
-#include "midd_internal.h"
+#include "f16x3_common.h"
 #include <cstdlib>
 #include <type_traits>
 #ifdef MIDD_CONV_TIMING
@@ -37,51 +37,6 @@
 #endif
 
 namespace midd {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
-constexpr float ACT_PRESCALE = 16.0f;             // 2^s, s = 4 (see header); must match midd_api.hip
-
-__device__ __forceinline__ float silu16(float v) {
-    // x * 1/(1+2^(-x*log2 e)) on v_exp_f32 / v_rcp_f32 (~1 ulp each)
-    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
-}
-
-// Sum over the 16 lanes of a DPP row (lanes 16r..16r+15) with four rotate-and-add steps on the
-// VALU (row_ror:8,4,2,1): every lane ends with the row total; the order is fixed per lane.
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
-}
-
-__device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e] * ACT_PRESCALE;
-        const _Float16 h = (_Float16)x;
-        hi[e] = h;
-        lo[e] = (_Float16)(x - (float)h);
-    }
-}
-
-// Wait until at most N of this wave's vector-memory operations (all of them LDS-DMA inside the
-// K loop) are outstanding and all its LDS accesses are done, then the workgroup barrier.
-template <int N>
-__device__ __forceinline__ void wait_vm_and_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
-    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
-                                     (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
-}
 
 template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 struct Conv16Geom {
@@ -555,7 +510,6 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------ dispatch
-static int conv16_wgs_per_img(int tiles, int B, int ny);
 #ifdef MIDD_CONV_TIMING
 static std::vector<std::string> g_timing_names;
 static int conv_timing_slot(int ks, int st, int tw, int mt, int nt, int wm, int wn, int oh, int cin, int cout, int B, int ring, int wgs) {
@@ -616,7 +570,7 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
 }
 
 // ~3 resident workgroups per CU; a sample's tiles are dealt evenly to its persistent workgroups
-static int conv16_wgs_per_img(int tiles, int B, int ny) {
+int conv16_wgs_per_img(int tiles, int B, int ny) {
     static const int target_wgs = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 768;
     int per_img = target_wgs / (B * ny);
     if (per_img < 1) per_img = 1;
@@ -626,6 +580,10 @@ static int conv16_wgs_per_img(int tiles, int B, int ny) {
 }
 
 int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout) {
+    if (compute_mode == MODE_F16X3 && t.tw == 0) {           // flattened-pixel 1x1 kernel
+        const int bm1 = t.wm * t.mt * 16;
+        return conv16_wgs_per_img((OH * OW + bm1 - 1) / bm1, B, Cout / (t.wn * t.nt * 16)) * t.wm;
+    }
     const int bm = t.wm * t.mt * 16, th = bm / t.tw;
     const int tiles = ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th);
     if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16)) * t.wm;
@@ -667,6 +625,7 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
 bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t) {
     if (Cout % 16) return false;
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
+    if (ks == 1 && conv1x1_pick_tile(Cin, Cout, B, OH, OW, t)) return true;      // dedicated 1x1 kernel (conv1x1_f16x3.hip)
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const int nn = Cout / (16 * nt);                      // cout slices of 16*nt; a workgroup takes wn of them
     const Tile16* best = nullptr;
@@ -714,6 +673,7 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
 }
 
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
+    if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
         if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \

@@ -54,6 +54,9 @@ int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, i
 
 // split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
 bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
+int conv16_wgs_per_img(int tiles, int B, int ny);
+bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t);   // ConvTile::tw == 0 marks it
+hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);      // persistent workgroups per sample (f16x3 kernels)
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 // 16-channel blocks staged per K chunk of the f16x3 kernel (shared with the host packer).
 //   3x3: 1 -> 16 channels per chunk, two taps per MFMA step (10 % padded MFMA slots, but half the
