@@ -211,15 +211,18 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         if (s + 1 < total) compute(ra[1], s + 3 < total);
     }
 
-    // ---- publish the GroupNorm partial sums: one row per (workgroup, wave) ---------------------------
-    if (a.stat_partial != nullptr && p16 == 0) {
-        const int row = first_tile * G::NW + wave;
+    // ---- publish the GroupNorm partial sums: one row per workgroup (the waves' rows folded in a fixed order) ----
+    if (a.stat_partial != nullptr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        constexpr int ROWF = 2 * NT * 16;
+        for (int i = tid; i < ROWF; i += G::NTHREADS) {
+            const int which = i / (NT * 16), c = i - which * (NT * 16);
+            float t = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (ntile0 + nt) * 16 + kq * 4;
-            float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
-            *reinterpret_cast<f32x4*>(pr) = *reinterpret_cast<const f32x4*>(my_stat + nt * 16);
-            *reinterpret_cast<f32x4*>(pr + a.Cout) = *reinterpret_cast<const f32x4*>(my_stat + NT * 16 + nt * 16);
+            for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
+            a.stat_partial[((size_t)(b * a.stat_rows + first_tile) * 2 + which) * a.Cout + ntile_wg * 16 + c] = t;
         }
     }
 }

@@ -413,15 +413,21 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             }
         }
     };
+    // one row per workgroup: the waves' LDS rows are folded over wm in a fixed order after a barrier
     auto publish_stats = [&]() {
-        if (a.stat_partial == nullptr || p16 != 0) return;
-        const int row = (blockIdx.x - b * a.wgs_per_img) * WM + wm;
+        if (a.stat_partial == nullptr) return;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int row = blockIdx.x - b * a.wgs_per_img;
+        constexpr int ROWF = 2 * NT * 16;                              // floats of one wave's row
+        for (int i = tid; i < WN * ROWF; i += NTHREADS) {
+            const int wn_i = i / ROWF, r = i - wn_i * ROWF;
+            const int which = r / (NT * 16), c = r - which * (NT * 16);
+            float t = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (ntile0 + nt) * 16 + kq * 4;
-            float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
-            *reinterpret_cast<f32x4*>(pr) = *reinterpret_cast<const f32x4*>(my_stat + nt * 16);
-            *reinterpret_cast<f32x4*>(pr + a.Cout) = *reinterpret_cast<const f32x4*>(my_stat + NT * 16 + nt * 16);
+            for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
+            a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + (ntile_wg + wn_i * NT) * 16 + c] = t;
         }
     };
 
@@ -582,11 +588,11 @@ int conv16_wgs_per_img(int tiles, int B, int ny) {
 int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout) {
     if (compute_mode == MODE_F16X3 && t.tw == 0) {           // flattened-pixel 1x1 kernel
         const int bm1 = t.wm * t.mt * 16;
-        return conv16_wgs_per_img((OH * OW + bm1 - 1) / bm1, B, Cout / (t.wn * t.nt * 16)) * t.wm;
+        return conv16_wgs_per_img((OH * OW + bm1 - 1) / bm1, B, Cout / (t.wn * t.nt * 16));
     }
     const int bm = t.wm * t.mt * 16, th = bm / t.tw;
     const int tiles = ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th);
-    if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16)) * t.wm;
+    if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16));   // one row per workgroup
     return tiles * t.wm;
 }
 
