@@ -128,6 +128,8 @@ void gn_from_partial_kernel(const GnFromPartialArgs a) {
     const int nrl = GNF_THREADS / cg;                 // row lanes
     const int ci = tid % cg, rl = tid / cg;
     double s1 = 0, s2 = 0;
+    float gam = 0.f, bet = 0.f;                        // requested up front: off the dependent chain at the end
+    if (tid < cg) { gam = a.gamma[g * cg + tid]; bet = a.beta[g * cg + tid]; }
     if (rl < nrl) {
         const int c = g * cg + ci;
         const float* p; int rows, Cs, cl;
@@ -153,6 +155,30 @@ void gn_from_partial_kernel(const GnFromPartialArgs a) {
     }
     red[tid][0] = s1; red[tid][1] = s2;
     __syncthreads();
+    if (cg <= 64) {
+        // latency path (every configuration of this model): the first wave folds the row lanes per channel,
+        // then the channels with fixed-order cross-lane adds; every lane ends with the group totals, so there
+        // is no second barrier and no broadcast through LDS
+        if (tid < 64) {
+            double t1 = 0, t2 = 0;
+            if (tid < cg)
+                for (int l = 0; l < nrl; ++l) { t1 += red[l * cg + tid][0]; t2 += red[l * cg + tid][1]; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { t1 += __shfl_xor(t1, off, 64); t2 += __shfl_xor(t2, off, 64); }
+            if (tid < cg) {
+                const double n = (double)a.HW * cg;
+                const double mean = t1 / n;
+                double var = t2 / n - mean * mean;
+                if (var < 0) var = 0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+                const int c = g * cg + tid;
+                const float sc = rstd * gam;
+                a.scale[(size_t)b * C + c] = sc;
+                a.shift[(size_t)b * C + c] = bet - (float)mean * sc;
+            }
+        }
+        return;
+    }
     if (tid < cg) {                                    // fold row lanes, fixed order
         double t1 = 0, t2 = 0;
         for (int l = 0; l < nrl; ++l) { t1 += red[l * cg + tid][0]; t2 += red[l * cg + tid][1]; }
@@ -172,9 +198,9 @@ void gn_from_partial_kernel(const GnFromPartialArgs a) {
     __syncthreads();
     if (tid < cg) {
         const int c = g * cg + tid;
-        const float sc = s_mr[1] * a.gamma[c];
+        const float sc = s_mr[1] * gam;
         a.scale[(size_t)b * C + c] = sc;
-        a.shift[(size_t)b * C + c] = a.beta[c] - s_mr[0] * sc;
+        a.shift[(size_t)b * C + c] = bet - s_mr[0] * sc;
     }
 }
 
