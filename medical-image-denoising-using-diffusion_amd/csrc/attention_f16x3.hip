@@ -87,7 +87,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
                             float* __restrict__ out, int N, int Npad, int C, float qscale) {
     constexpr int DC = D / 32;                 // 32-wide k chunks of the head dimension (QK^T)
     constexpr int DT = D / 16;                 // 16-row output tiles of O^T
-    constexpr int KLD = D + 8;                 // K image row (halfs): [key][d]
+    constexpr int KLD = D + 16;                // K image row (halfs): [key][d]; 224-B rows make the ds_read_b128 fragment reads conflict-free (D + 8: 2-way)
     constexpr int VLD = A16_KT + 8;            // V^T image row (halfs): [d][key]
     constexpr int KB = A16_KT / 16;
     static_assert(D % 32 == 0, "head_dim must be a multiple of 32");
