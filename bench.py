@@ -37,9 +37,13 @@ PEAK_HBM = 8.0e12
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes
-    (profiles/r01c_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
+    (profiles/*_pmc_traffic.json, newest: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
     corrections applied as MI355X_MICROARCH.md prescribes), or None."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not found:
+        return None
+    path = found[-1]                      # newest round's passes (tools/profile_round.sh)
     try:
         with open(path) as f:
             k = json.load(f)["kernels"].get(kernel_name)

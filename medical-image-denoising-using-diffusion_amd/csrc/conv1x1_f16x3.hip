@@ -25,7 +25,7 @@ struct Conv1Geom {
     static constexpr int WSTEP = NT * 2048;                  // bytes of one K-step's weights (hi + lo, NT cout tiles)
     static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
     static constexpr int ADD_FLOATS = NT * 16;
-    static int lds_bytes(int cin) { return ((cin + 31) / 32) * WSTEP + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4; }
+    static int lds_bytes(int cin) { return ((cin + 31) / 32) * WSTEP + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
 };
 
 template <int MT, int NT>
@@ -89,7 +89,9 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             dma16(wbase + step * wstep_bytes + r * 1024, wl + piece * 1024);
         }
     }
-    if (a.prologue != PRO_RAW) {
+    if (a.prologue != PRO_RAW && a.gn_part0 != nullptr) {
+        gn_finalize_lds(a, b, gnp, ACT_PRESCALE, tid, G::NTHREADS);
+    } else if (a.prologue != PRO_RAW) {
         for (int i = tid; i < Cin; i += G::NTHREADS) {
             gnp[i] = a.gn_scale[(size_t)b * Cin + i] * ACT_PRESCALE;     // the prescale is folded into the affine (exact)
             gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i] * ACT_PRESCALE;

@@ -65,7 +65,7 @@ struct Conv16Geom {
     // GroupNorm scale/shift of the input, [2][Cin] floats, sized at launch (dynamic LDS); the ring is
     // dimensioned for up to NOMINAL_CIN input channels (more still runs, possibly one workgroup per CU fewer)
     static constexpr int NOMINAL_CIN = 384;
-    static constexpr int FIXED_BYTES = RAW_BYTES + IMG_BYTES + EPI_BYTES + 2 * NOMINAL_CIN * 4;
+    static constexpr int FIXED_BYTES = RAW_BYTES + IMG_BYTES + EPI_BYTES + 2 * NOMINAL_CIN * 4 + 64;
     // weight steps resident in LDS (prefetch distance RING-1): L2->LDS latency is ~1-2k cycles under
     // load, a step is only 150-600 MFMA cycles, so take as many slots as fit in half the LDS (two
     // workgroups per CU), between 2 and 6.
@@ -81,7 +81,7 @@ struct Conv16Geom {
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;                 // at NOMINAL_CIN
-    static constexpr int lds_bytes(int cin) { return LDS_BYTES + 2 * (cin - NOMINAL_CIN) * 4; }
+    static constexpr int lds_bytes(int cin) { return LDS_BYTES + 2 * (cin - NOMINAL_CIN) * 4; }   // incl. the 16 mean/rstd floats
     static_assert(BM % TW == 0, "tile");
 };
 
@@ -284,9 +284,13 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
     if (a.prologue != PRO_RAW) {
-        for (int i = tid; i < Cin; i += NTHREADS) {
-            gnp[i] = a.gn_scale[(size_t)b * Cin + i];
-            gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i];
+        if (a.gn_part0 != nullptr) {
+            gn_finalize_lds(a, b, gnp, 1.0f, tid, NTHREADS);
+        } else {
+            for (int i = tid; i < Cin; i += NTHREADS) {
+                gnp[i] = a.gn_scale[(size_t)b * Cin + i];
+                gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i];
+            }
         }
     }
     for (int i = tid; i < G::STAT_FLOATS; i += NTHREADS) stat_lds[i] = 0.f;
@@ -621,7 +625,7 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int cb = conv16_cb(ks);
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
-    const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4;
+    const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4 + 64;
     long ring = (((d.nt > 3 || d.mt > 2) ? 80 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;

@@ -18,7 +18,7 @@ namespace midd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GN_THREADS = 256;
-constexpr int GN_GROUPS_ = 8;
+// GN_GROUPS_ (8, nn.GroupNorm(8, C)) is defined in midd_internal.h
 
 __global__ __launch_bounds__(GN_THREADS)
 void gn_partial_kernel(const GnArgs a) {

@@ -77,6 +77,8 @@ struct Op {
     int stride = 1, ks = 3;
     bool want_stats = false;
     float out_scale = 1.f;
+    int gn_op_plus1 = 0;        // OP_CONV (f16x3): index + 1 of the GroupNorm op finalized inside this conv's prologue
+    bool fused = false;         // OP_GN: no launch of its own (see gn_op_plus1)
 };
 
 struct Program {
@@ -553,6 +555,14 @@ struct Builder {
         Op o{}; o.kind = OP_CONV; o.out_scale = wscale; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
         if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
+        // Opt-in (MIDD_GN_FUSE=1): measured at B=8, 256x256 the 51 saved launches per iteration are paid back by the
+        // longer prologue of every conv workgroup -- neutral unsplit (39.1 vs 39.1 img/s), -3 % with the default
+        // two-stream split, where the small finalize kernels already overlap the other half-batch.
+        static const bool fuse_gn = getenv("MIDD_GN_FUSE") && atoi(getenv("MIDD_GN_FUSE")) != 0;
+        if (gn_op >= 0 && fuse_gn && p->cfg.compute_mode == MI_COMPUTE_F16X3) {
+            g->ops[gn_op].fused = true;          // this conv is the GroupNorm's only consumer
+            o.gn_op_plus1 = gn_op + 1;
+        }
         if (resid) { o.resid = *resid; o.has_resid = true; }
         const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
                             ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
@@ -741,9 +751,12 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             break;
         case OP_CHAN_PART: *name = "midd::chan_partial_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
         case OP_CONV: {
-            snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
-                     p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
-                     o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn);
+            if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
+                snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d>", o.tile.mt, o.tile.nt);
+            else
+                snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
+                         p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
+                         o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn);
             *name = buf;
             const double cin = o.s0.C + (o.has_s1 ? o.s1.C : 0);
             *flops = 2.0 * elems(o.dst) * cin * o.ks * o.ks;
@@ -778,6 +791,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
     for (const Op& o : g->ops) {
+        if (o.kind == OP_GN && o.fused) continue;              // finalized in its consumer's prologue
         hipError_t e = hipSuccess;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (p->profiling) {
@@ -816,6 +830,12 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue;
                 if (o.prologue != PRO_RAW) { a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off); }
+                if (o.gn_op_plus1) {
+                    const Op& n = g->ops[o.gn_op_plus1 - 1];
+                    a.gn_part0 = F(n.s0.stat_off); a.gn_rows0 = n.s0.stat_rows;
+                    a.gn_part1 = n.has_s1 ? F(n.s1.stat_off) : nullptr; a.gn_rows1 = n.has_s1 ? n.s1.stat_rows : 0;
+                    a.gn_gamma = wd + n.gamma; a.gn_beta = wd + n.beta; a.gn_eps = 1e-5f; a.gn_hw = n.s0.H * n.s0.W;
+                }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
                 a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;

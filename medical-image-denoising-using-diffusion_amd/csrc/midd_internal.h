@@ -35,6 +35,11 @@ struct ConvArgs {
     int stat_rows;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
+    // f16x3 kernels: GroupNorm finalize fused into the prologue.  gn_part0 != nullptr: the workgroup derives
+    // scale/shift of ITS sample from the producers' partial sums [B][rows][2][C] itself (fixed order, so every
+    // workgroup gets identical values) instead of reading gn_scale/gn_shift written by gn_from_partial_kernel.
+    const float* gn_part0; const float* gn_part1; int gn_rows0, gn_rows1;
+    const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_hw;
 #ifdef MIDD_CONV_TIMING
     int dbg_slot;           // diagnostic build: row of g_conv_timing
 #endif
@@ -87,6 +92,7 @@ int gn_pick_nsplit(int B, int HW, int C);
 
 // GroupNorm from per-channel partial sums (produced by conv epilogues or chan_partial_launch):
 // up to two sources (torch.cat), each [B][rows][2][C].
+constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
 struct GnFromPartialArgs {
     const float* part0; int rows0, C0;
     const float* part1; int rows1, C1;
