@@ -142,6 +142,28 @@ int mi_profile_end(mi_plan* plan, mi_profile_entry* out, int max_entries, int* n
 
 void mi_plan_destroy(mi_plan* plan);
 
+/* ---- pre/post-processing either side of the sampler, on the device (no plan needed) -----------------------
+ * All pointers are device pointers; `stream` is a hipStream_t (NULL = default stream); calls are asynchronous.
+ *
+ * mi_resize_bicubic_u8: `n` 8-bit single-channel images [n][sh][sw] -> [n][dh][dw], bit-identical to Pillow's
+ *   `Image.resize((dw, dh), Image.BICUBIC)` on an 'L' image, i.e. to `transforms.Resize((dh, dw), BICUBIC)` on a
+ *   PIL input (Backend/run.py:146,198; Backend/cddpm/cddpmModels.py:488,502).  `workspace` needs
+ *   mi_resize_workspace_bytes(n, sw, sh, dw, dh) bytes, 256-byte aligned.
+ * mi_u8_to_unit_f32: `transforms.ToTensor()` on uint8 data: x / 255 in fp32 (run.py:199).
+ * mi_unit_f32_to_u8: `(clamp(x, 0, 1) * 255).astype('uint8')` (run.py:107,145): fp32 multiply, truncation.
+ * mi_image_metrics: `compute_metrics` (Backend/DDIM/DDIMModel.py:290-300): per image PSNR and SSIM of
+ *   clip(pred, 0, 1) against clip(target, 0, 1) with data_range = 1 (skimage defaults: 7x7 uniform window,
+ *   K1 = 0.01, K2 = 0.03, sample covariance, mean over the interior); fp32 images [n][h][w], h, w >= 7;
+ *   out: device double [n][2] = (psnr, ssim); workspace: mi_metrics_workspace_bytes(n, h) bytes. */
+size_t mi_resize_workspace_bytes(int n, int sw, int sh, int dw, int dh);
+int mi_resize_bicubic_u8(const void* src_u8, int n, int sw, int sh, void* dst_u8, int dw, int dh,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int mi_u8_to_unit_f32(const void* src_u8, void* dst_f32, size_t count, void* stream);
+int mi_unit_f32_to_u8(const void* src_f32, void* dst_u8, size_t count, void* stream);
+size_t mi_metrics_workspace_bytes(int n, int h);
+int mi_image_metrics(const void* target_f32, const void* pred_f32, int n, int h, int w, void* out_f64,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* Thread-local, never NULL. */
 const char* mi_last_error(void);
 

@@ -223,6 +223,43 @@ static int build_topology(mi_plan* p) {
     return MI_OK;
 }
 
+// ------------------------------------------------------------------------------ C ABI: pre/post-processing
+extern "C" size_t mi_resize_workspace_bytes(int n, int sw, int sh, int dw, int dh) {
+    if (n < 1 || sw < 1 || sh < 1 || dw < 1 || dh < 1) return 0;
+    return resize_workspace_bytes(n, sw, sh, dw, dh);
+}
+extern "C" int mi_resize_bicubic_u8(const void* src, int n, int sw, int sh, void* dst, int dw, int dh,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!src || !dst || !workspace) return fail(MI_EINVAL, "null argument");
+    if (n < 1 || sw < 1 || sh < 1 || dw < 1 || dh < 1) return fail(MI_EINVAL, "image sizes must be positive");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(MI_EINVAL, "workspace must be 256-byte aligned");
+    if (workspace_bytes < resize_workspace_bytes(n, sw, sh, dw, dh))
+        return fail(MI_EINVAL, "workspace too small: %zu < %zu", workspace_bytes, resize_workspace_bytes(n, sw, sh, dw, dh));
+    HIPCHK(resize_bicubic_u8_launch(static_cast<const unsigned char*>(src), n, sw, sh, static_cast<unsigned char*>(dst), dw, dh,
+                                    workspace, static_cast<hipStream_t>(stream)));
+    return MI_OK;
+}
+extern "C" int mi_u8_to_unit_f32(const void* src, void* dst, size_t count, void* stream) {
+    if (!src || !dst) return fail(MI_EINVAL, "null argument");
+    HIPCHK(u8_to_unit_launch(static_cast<const unsigned char*>(src), static_cast<float*>(dst), count, static_cast<hipStream_t>(stream)));
+    return MI_OK;
+}
+extern "C" int mi_unit_f32_to_u8(const void* src, void* dst, size_t count, void* stream) {
+    if (!src || !dst) return fail(MI_EINVAL, "null argument");
+    HIPCHK(unit_to_u8_launch(static_cast<const float*>(src), static_cast<unsigned char*>(dst), count, static_cast<hipStream_t>(stream)));
+    return MI_OK;
+}
+extern "C" size_t mi_metrics_workspace_bytes(int n, int h) { return (n < 1 || h < 1) ? 0 : metrics_workspace_bytes(n, h); }
+extern "C" int mi_image_metrics(const void* target, const void* pred, int n, int h, int w, void* out,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (!target || !pred || !out || !workspace) return fail(MI_EINVAL, "null argument");
+    if (n < 1 || h < 7 || w < 7) return fail(MI_EINVAL, "images must be at least 7x7 (SSIM window), got %dx%d", h, w);
+    if (workspace_bytes < metrics_workspace_bytes(n, h)) return fail(MI_EINVAL, "workspace too small");
+    HIPCHK(metrics_launch(static_cast<const float*>(target), static_cast<const float*>(pred), n, h, w, static_cast<double*>(out),
+                          workspace, static_cast<hipStream_t>(stream)));
+    return MI_OK;
+}
+
 // ------------------------------------------------------------------------------ C ABI: create / load
 extern "C" const char* mi_last_error(void) { return g_err; }
 extern "C" const char* mi_version(void) { return "midd 0.2 gfx950 (fp32 MFMA | split-fp16 x3 MFMA)"; }

@@ -105,6 +105,14 @@ hipError_t gn_from_partial_launch(const GnFromPartialArgs& a, hipStream_t s);
 hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
+// ---------------------------------------------------------------- pre/post-processing (prepost.hip)
+size_t resize_workspace_bytes(int n, int sw, int sh, int dw, int dh);
+hipError_t resize_bicubic_u8_launch(const unsigned char* src, int n, int sw, int sh, unsigned char* dst, int dw, int dh, void* ws, hipStream_t s);
+hipError_t u8_to_unit_launch(const unsigned char* src, float* dst, size_t count, hipStream_t s);
+hipError_t unit_to_u8_launch(const float* src, unsigned char* dst, size_t count, hipStream_t s);
+size_t metrics_workspace_bytes(int n, int h);
+hipError_t metrics_launch(const float* target, const float* pred, int n, int h, int w, double* out, void* ws, hipStream_t s);
+
 // ---------------------------------------------------------------- attention
 // qkv: NHWC [B][N][3C], channel = s*C + head*D + d (s in q,k,v);  out: [B][N][C]
 hipError_t attention_launch(const float* qkv, float* out, int B, int N, int C, int heads, hipStream_t s);

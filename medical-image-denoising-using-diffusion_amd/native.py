@@ -58,6 +58,14 @@ SYMBOLS = [
                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
     ("mi_profile_begin", C.c_int, [C.c_void_p]),
     ("mi_profile_end", C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
+    ("mi_resize_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("mi_resize_bicubic_u8", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("mi_u8_to_unit_f32", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("mi_unit_f32_to_u8", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("mi_metrics_workspace_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("mi_image_metrics", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mi_plan_destroy", None, [C.c_void_p]),
     ("mi_last_error", C.c_char_p, []),
     ("mi_version", C.c_char_p, []),

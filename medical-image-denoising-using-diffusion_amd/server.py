@@ -12,7 +12,9 @@ Contract kept from /root/reference/Backend/run.py:
   * ``GET /health`` (run.py:215-226) and ``GET /`` (run.py:166-175).
   * checkpoint dict ``{'model_state_dict', 'noise_steps', ...}`` (run.py:37-41), loaded with
     ``weights_only=True`` (nothing from the file is executed).
-The sampler call runs in a worker thread (``asyncio.to_thread``, as run.py:85) on the GPU.
+The sampler call runs in a worker thread (``asyncio.to_thread``, as run.py:85) on the GPU.  On a GPU service the
+resizes, the ToTensor scaling and the uint8 conversion also run on the device (``prepost``; bit-identical to the
+PIL / numpy recipe, which stays as ``preprocess`` / ``tensor_to_base64`` for CPU tensors and tests).
 
 ``python-multipart`` is not available in this image, so the multipart body is parsed with the
 standard library instead of FastAPI's ``UploadFile``; the wire format is the same.
@@ -56,6 +58,27 @@ def tensor_to_base64(tensor: torch.Tensor, size: Tuple[int, int]) -> str:
     output_img = output_img.resize(size, Image.BICUBIC)
     buffered = io.BytesIO()
     output_img.save(buffered, format="PNG")
+    return base64.b64encode(buffered.getvalue()).decode()
+
+
+def preprocess_device(image_bytes: bytes, device: torch.device) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    """`preprocess` with the resize and the ToTensor scaling on the GPU (csrc/prepost.hip; bit-identical to the
+    host recipe): only the PNG/JPEG decode stays on the host."""
+    from . import prepost
+    image = Image.open(io.BytesIO(image_bytes)).convert("L")
+    original_size = image.size
+    raw = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).to(device, non_blocking=True)
+    resized = prepost.resize_bicubic_u8(raw, SERVE_SIZE)
+    return prepost.to_unit_float(resized)[None, None], original_size
+
+
+def tensor_to_base64_device(tensor: torch.Tensor, size: Tuple[int, int]) -> str:
+    """`tensor_to_base64` with clamp / x255 truncation / resize-back on the GPU; PNG encoding on the host."""
+    from . import prepost
+    u8 = prepost.to_u8(tensor.reshape(tensor.shape[-2], tensor.shape[-1]).float())
+    back = prepost.resize_bicubic_u8(u8, (size[1], size[0])).cpu().numpy()      # PIL size is (width, height)
+    buffered = io.BytesIO()
+    Image.fromarray(back, mode="L").save(buffered, format="PNG")
     return base64.b64encode(buffered.getvalue()).decode()
 
 
@@ -105,7 +128,7 @@ class DiffusionService:
             else:
                 output = self.diffusion_denoiser.denoise(input_tensor, inference_steps=SERVE_INFERENCE_STEPS)
             output = torch.clamp(output, 0, 1)
-            result = tensor_to_base64(output, original_size)
+            result = (tensor_to_base64_device if output.is_cuda else tensor_to_base64)(output, original_size)
         print(f"  Diffusion: {time.time() - start:.2f}s")
         return result
 
@@ -118,8 +141,15 @@ class DiffusionService:
 
     def denoise_bytes(self, image_bytes: bytes) -> dict:
         """Synchronous helper: the whole request path without HTTP."""
+        x, size = self.preprocess(image_bytes)
+        return asyncio.run(self.process_all_models(x, size))
+
+    def preprocess(self, image_bytes: bytes) -> Tuple[torch.Tensor, Tuple[int, int]]:
+        """Decode + resize + scale; on the GPU when the service runs there (same bytes either way)."""
+        if self.device.type == "cuda" and self._denoise_fn is None:
+            return preprocess_device(image_bytes, self.device)
         x, size = preprocess(image_bytes)
-        return asyncio.run(self.process_all_models(x.to(self.device), size))
+        return x.to(self.device), size
 
 
 def create_app(service: Optional[DiffusionService] = None, checkpoint: Optional[str] = None):
@@ -152,8 +182,8 @@ def create_app(service: Optional[DiffusionService] = None, checkpoint: Optional[
         try:
             total_start = time.time()
             image_data = extract_multipart_file(await request.body(), request.headers.get("content-type", ""))
-            input_tensor, original_size = preprocess(image_data)
-            results = await svc.process_all_models(input_tensor.to(svc.device), original_size)
+            input_tensor, original_size = svc.preprocess(image_data)
+            results = await svc.process_all_models(input_tensor, original_size)
             print(f"Total request time: {time.time() - total_start:.2f}s")
             return JSONResponse(content=results)
         except Exception as e:                                   # run.py:210-213

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "midd.h")).read()
-    declared = set(re.findall(r"\b(mi_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     lib = native.lib()
     bound = {n for n, _, _ in native.SYMBOLS}

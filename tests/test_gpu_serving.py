@@ -11,7 +11,8 @@ from PIL import Image
 
 from midd_amd import UNetConfig, topology
 from midd_amd.cli import denoise_image_diffusion
-from midd_amd.server import DiffusionService, create_app, preprocess
+from midd_amd.server import (DiffusionService, create_app, preprocess, preprocess_device, tensor_to_base64,
+                             tensor_to_base64_device)
 from midd_amd.weights import make_state_dict, synthetic_xray
 from oracle import ddim_oracle as orc
 
@@ -47,6 +48,19 @@ def test_denoise_route_matches_oracle_pipeline(tmp_path):
     diff = np.abs(got.astype(np.int32) - np.asarray(ref_img).astype(np.int32))
     # |delta| < 1e-3 in [0,1] can move a truncated 8-bit level by at most one step
     assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())
+
+
+def test_device_pre_and_post_processing_equal_the_host_recipe():
+    """run.py:143-149,193-201 on the GPU (csrc/prepost.hip) vs PIL / numpy on the host: same bytes."""
+    for (w, h) in [(200, 152), (1024, 768), (512, 512), (333, 517)]:
+        data = _png_bytes(w, h, seed=w + h)
+        x_host, size_host = preprocess(data)
+        x_dev, size_dev = preprocess_device(data, torch.device("cuda"))
+        assert size_host == size_dev == (w, h)
+        assert torch.equal(x_dev.cpu(), x_host)
+        out = torch.from_numpy(synthetic_xray(1, 512, 512, seed=w)).clamp(0, 1) * 1.1 - 0.05   # leaves [0,1] in places
+        out = torch.clamp(out, 0, 1)
+        assert tensor_to_base64_device(out.cuda(), (w, h)) == tensor_to_base64(out, (w, h))
 
 
 def test_cli_helper_cddpm_replay(tmp_path):
