@@ -41,8 +41,14 @@ def denoise_image_diffusion(model_path: Optional[str], test_image_path: str, dev
     print(f"Loaded model - PSNR: {checkpoint.get('best_psnr', 'N/A')} dB | SSIM: {checkpoint.get('best_ssim', 'N/A')}")
 
     img = Image.open(test_image_path).convert("L")
-    resized = img.resize((img_size, img_size), Image.BICUBIC)           # transforms.Resize on a PIL image
-    input_tensor = torch.from_numpy(np.asarray(resized, np.uint8).astype(np.float32) / 255.0)[None, None].to(device)
+    on_gpu = device.type == "cuda"
+    if on_gpu:      # resize + ToTensor scaling on the device (prepost: bit-identical to the PIL / numpy recipe below)
+        from . import prepost
+        raw = torch.from_numpy(np.asarray(img, np.uint8).copy()).to(device)
+        input_tensor = prepost.to_unit_float(prepost.resize_bicubic_u8(raw, (img_size, img_size)))[None, None]
+    else:
+        resized = img.resize((img_size, img_size), Image.BICUBIC)       # transforms.Resize on a PIL image
+        input_tensor = torch.from_numpy(np.asarray(resized, np.uint8).astype(np.float32) / 255.0)[None, None].to(device)
 
     start_time = time.time()
     kw = {"step_noise": step_noise} if step_noise is not None else {}
@@ -51,6 +57,9 @@ def denoise_image_diffusion(model_path: Optional[str], test_image_path: str, dev
         torch.cuda.synchronize(device)
     print(f"Inference time: {time.time() - start_time:.2f} seconds")
 
+    if on_gpu:
+        u8 = prepost.to_u8(denoised.reshape(img_size, img_size).float())     # denoise() already clamped to [0, 1]
+        return Image.fromarray(prepost.resize_bicubic_u8(u8, (img.size[1], img.size[0])).cpu().numpy(), mode="L")
     output_np = denoised.squeeze().cpu().numpy()
     output_img = Image.fromarray((output_np * 255).astype(np.uint8), mode="L")
     return output_img.resize(img.size, Image.BICUBIC)
