@@ -237,7 +237,7 @@ static hipError_t launch1(const ConvArgs& a0, hipStream_t s) {
     a.tiles_x = (HW + G::BM - 1) / G::BM;
     a.tiles_y = 1;
     const int ny = a.Cout / (NT * 16);
-    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x, a.B, ny);
+    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x, a.B, ny, a.persist_wgs);
     const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (lds_bytes > 64 * 1024) {
@@ -259,7 +259,8 @@ bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t) {
     if (!enabled || Cout % 16 || Cin % 16) return false;
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const long wgs2 = (long)B * ((OH * OW + 127) / 128) * (Cout / (16 * nt));
-    const int mt = wgs2 >= 512 ? 2 : 1;                      // small maps: 64-pixel tiles, twice the workgroups
+    static const long mt2_wgs = getenv("MIDD_C1_MT2_WGS") ? atol(getenv("MIDD_C1_MT2_WGS")) : 512;
+    const int mt = wgs2 >= mt2_wgs ? 2 : 1;                  // small maps: 64-pixel tiles, twice the workgroups
     if (((Cin + 31) / 32) * nt * 2048 + 8 * Cin + 4096 > 150 * 1024) return false;   // all weights must fit in LDS
     *t = ConvTile{1, 1, 0, mt, nt, 4, 1};
     return true;

@@ -554,7 +554,7 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + G::TH - 1) / G::TH;
     const int ny = a.Cout / (WN * NT * 16);
-    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny);
+    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny, a.persist_wgs);
     dim3 grid(a.B * a.wgs_per_img, ny);
 #ifdef MIDD_CONV_TIMING
     a.dbg_slot = conv_timing_slot(KS, STRIDE, TW, MT, NT, WM, WN, a.OH, a.C0 + a.C1, a.Cout, a.B, G::RING, (int)grid.x * (int)grid.y);
@@ -580,8 +580,9 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
 }
 
 // ~3 resident workgroups per CU; a sample's tiles are dealt evenly to its persistent workgroups
-int conv16_wgs_per_img(int tiles, int B, int ny) {
-    static const int target_wgs = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 768;
+int conv16_wgs_per_img(int tiles, int B, int ny, int target) {
+    static const int target_env = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 0;
+    const int target_wgs = target_env ? target_env : (target ? target : 768);
     int per_img = target_wgs / (B * ny);
     if (per_img < 1) per_img = 1;
     if (per_img > tiles) per_img = tiles;
@@ -589,14 +590,14 @@ int conv16_wgs_per_img(int tiles, int B, int ny) {
     return (tiles + tiles_per_wg - 1) / tiles_per_wg;
 }
 
-int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout) {
+int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout, int persist_wgs) {
     if (compute_mode == MODE_F16X3 && t.tw == 0) {           // flattened-pixel 1x1 kernel
         const int bm1 = t.wm * t.mt * 16;
-        return conv16_wgs_per_img((OH * OW + bm1 - 1) / bm1, B, Cout / (t.wn * t.nt * 16));
+        return conv16_wgs_per_img((OH * OW + bm1 - 1) / bm1, B, Cout / (t.wn * t.nt * 16), persist_wgs);
     }
     const int bm = t.wm * t.mt * 16, th = bm / t.tw;
     const int tiles = ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th);
-    if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16));   // one row per workgroup
+    if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16), persist_wgs);   // one row per workgroup
     return tiles * t.wm;
 }
 
@@ -652,7 +653,9 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
     static const int big_rule = getenv("MIDD_TILE_BIG") ? atoi(getenv("MIDD_TILE_BIG")) : 0;
     const bool big_ok = big_rule && ks == 3 && stride == 1 && Cin >= 96 && moved_mb <= 96.0 && wgs_mt4 >= 512;
     const int max_mt = max_mt_env ? max_mt_env : (big_ok ? 4 : 2);
-    static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 256;
+    // 192, not 256: at B=4 (half-batches) the 32x32 layers with 144 couts would otherwise drop to 32-pixel 2-wave
+    // tiles that stream the weights twice as often (same-box A/B: +1.7 %)
+    static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 192;
     static const int pix_first = getenv("MIDD_PIX_FIRST") ? atoi(getenv("MIDD_PIX_FIRST")) : 1;
     static const int wide_ok = getenv("MIDD_TILE_NT6") ? atoi(getenv("MIDD_TILE_NT6")) : 0;
     for (const Tile16& d : kTiles16) {

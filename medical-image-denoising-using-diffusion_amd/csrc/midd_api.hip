@@ -83,6 +83,7 @@ struct Op {
 
 struct Program {
     int B, H, W;
+    int persist_wgs = 0;       // f16x3 convs: persistent-workgroup target of this program (0 = default)
     std::vector<Op> ops;
     size_t bytes = 0, trow_off = 0, sched_off = 0, counter_off = 0;
     std::map<std::string, TensorRef> outputs;
@@ -606,7 +607,7 @@ struct Builder {
                             : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
         if (want_stats) {
-            dst.stat_rows = conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C);
+            dst.stat_rows = conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C, g->persist_wgs);
             dst.stat_off = bump.take((size_t)B * dst.stat_rows * 2 * dst.C * sizeof(float));
             o.want_stats = true;
         }
@@ -728,13 +729,18 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     return MI_OK;
 }
 
-static int get_program(mi_plan* p, int B, int H, int W, Program** out) {
+// side_by_side: the program runs next to another sub-batch's program on a second stream (mi_denoise split); its
+// convs then ask for fewer persistent workgroups (640 instead of 768: each kernel has about half the chip; same-box
+// A/B +2.5 % split, while an unsplit run loses 4 % with 640)
+static int get_program(mi_plan* p, int B, int H, int W, Program** out, bool side_by_side = false) {
     if (!p->finalized) return fail(MI_ESTATE, "mi_unet_finalize has not been called (or weights changed since)");
-    const uint64_t key = ((uint64_t)B << 40) ^ ((uint64_t)H << 20) ^ (uint64_t)W;
+    const uint64_t key = ((uint64_t)(side_by_side ? 1 : 0) << 63) ^ ((uint64_t)B << 40) ^ ((uint64_t)H << 20) ^ (uint64_t)W;
     std::lock_guard<std::mutex> lk(p->mu);
     auto it = p->programs.find(key);
     if (it == p->programs.end()) {
         std::unique_ptr<Program> g(new Program());
+        static const int side_wgs = getenv("MIDD_PERSIST_WGS_SPLIT") ? atoi(getenv("MIDD_PERSIST_WGS_SPLIT")) : 640;
+        g->persist_wgs = side_by_side ? side_wgs : 0;
         int rc = build_program(p, B, H, W, g.get());
         if (rc) return rc;
         it = p->programs.emplace(key, std::move(g)).first;
@@ -758,7 +764,7 @@ extern "C" size_t mi_workspace_bytes(mi_plan* plan, int B, int H, int W) {
     const int parts = split_parts(B);            // mi_denoise runs sub-batches side by side
     if (parts > 1) {
         Program* gh = nullptr;
-        if (get_program(plan, B / parts, H, W, &gh)) return 0;
+        if (get_program(plan, B / parts, H, W, &gh, true)) return 0;
         if (parts * gh->bytes > need) need = parts * gh->bytes;
     }
     return need;
@@ -877,6 +883,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
                 a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;
                 if (o.want_stats) { a.stat_partial = F(o.dst.stat_off); a.stat_rows = o.dst.stat_rows; }
+                a.persist_wgs = g->persist_wgs;
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
                 break;
             }
@@ -1052,7 +1059,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         // layers (one workgroup per CU at B=8) share the chip with another part's HBM-bound high-resolution
         // layers.
         Program* gh = nullptr;
-        if ((rc = get_program(plan, B / parts, H, W, &gh))) return rc;
+        if ((rc = get_program(plan, B / parts, H, W, &gh, true))) return rc;
         if (workspace_bytes < parts * gh->bytes) return fail(MI_ENOMEM, "workspace too small for the split run: need %zu bytes", parts * gh->bytes);
         std::lock_guard<std::mutex> lk(plan->side_mu);
         if (!plan->sev_fork) HIPCHK(hipEventCreateWithFlags(&plan->sev_fork, hipEventDisableTiming));

@@ -35,6 +35,7 @@ struct ConvArgs {
     int stat_rows;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
+    int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default), must match conv_stat_rows
     // f16x3 kernels: GroupNorm finalize fused into the prologue.  gn_part0 != nullptr: the workgroup derives
     // scale/shift of ITS sample from the producers' partial sums [B][rows][2][C] itself (fixed order, so every
     // workgroup gets identical values) instead of reading gn_scale/gn_shift written by gn_from_partial_kernel.
@@ -55,11 +56,11 @@ enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
 bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
 hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 // rows of the fused-statistics buffer one launch with this tile writes per image
-int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout);
+int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout, int persist_wgs = 0);
 
 // split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
 bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
-int conv16_wgs_per_img(int tiles, int B, int ny);
+int conv16_wgs_per_img(int tiles, int B, int ny, int target = 0);   // target 0: MIDD_PERSIST_WGS or 768
 bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t);   // ConvTile::tw == 0 marks it
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);      // persistent workgroups per sample (f16x3 kernels)
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
