@@ -268,10 +268,12 @@ bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTil
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
     int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const int nn = Cout / (16 * nt);                 // waves needed along cout
-    int wn = 1;
-    for (int cand = 4; cand >= 1; --cand)
-        if (nn % cand == 0) { wn = cand; break; }
-    // candidates with this (nt, wn): choose the largest pixel tile that still yields >= 2 workgroups per CU
+    // the widest instantiated wave layout along cout that divides nn (Cout = 128: nt 2, nn 4 -> wn 2), then the
+    // largest pixel tile that still yields >= 2 workgroups per CU
+    int wn = 0;
+    for (const TileDesc& d : kTiles)
+        if (d.nt == nt && nn % d.wn == 0 && d.wn > wn) wn = d.wn;
+    if (!wn) return false;
     const TileDesc* best = nullptr;
     long best_score = -(1L << 60);
     for (const TileDesc& d : kTiles) {

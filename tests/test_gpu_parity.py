@@ -230,6 +230,43 @@ def test_split_run_matches_oracle(variant):
 
 
 # ------------------------------------------------------------------------------ errors
+CONFIG_SWEEP = [
+    # (constructor kwargs, variant, B, H, W) -- only topologies whose skip stack closes in the reference itself and
+    # whose output keeps the input resolution (attention at the last level only), with head_dim in {32, 64, 96, 128}
+    (dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=2, attention_resolutions=(1,), time_emb_dim=32), "ddim", 2, 24, 24),
+    # 32..256 channels: concat inputs of up to 512 channels (LDS sized at launch beyond the nominal 384), head_dim 128,
+    # 2x2 maps at the lowest level
+    (dict(model_channels=32, channel_mult=(1, 2, 4, 8), num_res_blocks=2, attention_resolutions=(3,), time_emb_dim=64), "ddim", 1, 16, 16),
+    (dict(model_channels=64, channel_mult=(1, 1), num_res_blocks=3, attention_resolutions=(1,), time_emb_dim=48), "ddim", 3, 10, 14),
+    (dict(model_channels=32, channel_mult=(2, 2, 2, 2), num_res_blocks=3, attention_resolutions=(3,), time_emb_dim=40), "ddim", 2, 16, 24),
+    (dict(model_channels=32, channel_mult=(1, 2, 4), num_res_blocks=1, attention_resolutions=(2,), time_emb_dim=48), "cddpm", 3, 16, 24),
+    (dict(model_channels=48, channel_mult=(1, 2, 4), num_res_blocks=1, attention_resolutions=(2,), time_emb_dim=96), "cddpm", 2, 20, 12),
+    (dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1,), time_emb_dim=32), "cddpm", 1, 6, 10),
+    (dict(model_channels=16, channel_mult=(1, 2, 4, 8), num_res_blocks=1, attention_resolutions=(3,), time_emb_dim=32), "cddpm", 2, 16, 16),
+]
+
+
+@pytest.mark.parametrize("compute", COMPUTE_MODES)
+@pytest.mark.parametrize("case", range(len(CONFIG_SWEEP)))
+def test_other_topologies_forward_vs_oracle(case, compute):
+    """Planner + kernels on topologies other than the shipped one (the same classes serve the cddpm and hybrid
+    copies of the UNet, cddpmModels.py:176-265, hybrid3diffusionspeed.py:308-388): eps vs the oracle."""
+    kw, variant, B, H, W = CONFIG_SWEEP[case]
+    cfg = UNetConfig(variant=variant, **kw)
+    sd = make_state_dict(cfg, seed=100 + case)
+    m = _model(kw, sd, variant=variant, compute=compute)
+    rng = np.random.default_rng(case)
+    x = torch.from_numpy(rng.random((B, 1, H, W), dtype=np.float32))
+    cond = torch.from_numpy(synthetic_xray(B, H, W, seed=case))
+    t = torch.from_numpy(rng.integers(0, 50, B)).to(torch.int64)
+    ref = orc.unet_forward(orc.to_torch(sd), topology(cfg), x, cond, t).numpy()
+    assert ref.shape == (B, 1, H, W)
+    got = m(x.cuda(), cond.cuda(), t.cuda()).cpu().numpy()
+    d = _maxdiff(got, ref)
+    print(f"topology {case} {variant} {compute}: max|eps - oracle| = {d:.3e} (|eps| up to {np.abs(ref).max():.2f})")
+    assert d < TOL_EPS * max(1.0, float(np.abs(ref).max()))
+
+
 def test_error_behaviour():
     cfg = UNetConfig(**SMALL)
     model = _model(SMALL, make_state_dict(cfg, seed=1))
