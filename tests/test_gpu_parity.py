@@ -120,6 +120,25 @@ def test_per_sample_timesteps_and_batch_independence(compute):
         assert torch.equal(one[0], eps[i]), i
 
 
+@pytest.mark.parametrize("case", [(50, 8, 5, 24, 40), (20, 7, 6, 32, 16), (100, 100, 1, 16, 16), (10, 25, 2, 8, 8),
+                                  (50, 1, 3, 40, 24), (1000, 3, 4, 16, 32)])
+def test_sampler_schedules_and_batch_shapes_vs_oracle(case):
+    """`denoise` over noise_steps / inference_steps / batch / size combinations the serving paths do not use: more
+    inference steps than noise steps (stride clamps to 1), one step, 1000-row time table, odd batches (3 and 5 do
+    not split over two streams, 6 splits 3 + 3), non-square images (DDIMModel.py:268-289)."""
+    noise_steps, inference_steps, B, H, W = case
+    cfg = UNetConfig(**SMALL)
+    sd = make_state_dict(cfg, seed=11, perturb_norm=True)
+    model = _model(SMALL, sd)
+    noisy = torch.from_numpy(synthetic_xray(B, H, W, seed=noise_steps + B, kind="uniform"))
+    ref = orc.denoise(orc.to_torch(sd), topology(cfg), noisy, noise_steps=noise_steps, inference_steps=inference_steps)
+    out = DiffusionDenoiser(model, noise_steps=noise_steps).denoise(noisy.cuda(), inference_steps=inference_steps)
+    n_it = len(timestep_list(noise_steps, inference_steps))
+    d = _maxdiff(out.cpu().numpy(), ref.numpy())
+    print(f"schedule {case}: {n_it} iterations, max|d| = {d:.2e}")
+    assert d < TOL_FINAL
+
+
 # ------------------------------------------------------------------------------ full network
 def test_full_forward_64_vs_golden(full_model):
     cfg, sd, model = full_model
