@@ -216,6 +216,25 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         if (blk >= nblk) return;
         const int ch = (blk << 4) + (q8 & 3) * 4;
         // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
+        if (a.prologue == PRO_PRE) {        // operand words (hi | lo << 16) made by preact_kernel: unpack only
+            char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
+#pragma unroll
+            for (int s = 0; s < APW; ++s) {
+                const int slot = tid + s * NTHREADS;
+                if (g_off[s] > -2) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    u32x4 w = *reinterpret_cast<const u32x4*>(raw + slot * 16);
+                    if (g_off[s] < 0) w = (u32x4){0u, 0u, 0u, 0u};
+                    const u32x2 hi = {__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u)};
+                    const u32x2 lo = {__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u)};
+                    const int pix = slot / QPP;
+                    *reinterpret_cast<u32x2*>(base + pix * 32) = hi;
+                    *reinterpret_cast<u32x2*>(base + PLANE + pix * 32) = lo;
+                }
+            }
+            return;
+        }
         f32x4 sc = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
         if (a.prologue != PRO_RAW) {
             sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
@@ -283,7 +302,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     issue_a(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
-    if (a.prologue != PRO_RAW) {
+    if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU) {
         if (a.gn_part0 != nullptr) {
             gn_finalize_lds(a, b, gnp, 1.0f, tid, NTHREADS);
         } else {

@@ -260,6 +260,49 @@ hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------ pre-activation pass
+// One thread = 4 channels of one pixel.  Same arithmetic as the conv's in-kernel transform (conv_mfma_f16x3.hip):
+// v = x * (16 sc) + 16 sh, SiLU on the 16x-scaled value, hi = fp16(v), lo = fp16(v - hi).
+__global__ __launch_bounds__(256)
+void preact_kernel(const float* __restrict__ src0, int C0, const float* __restrict__ src1, int C1,
+                   const float* __restrict__ scale, const float* __restrict__ shift, int silu,
+                   unsigned* __restrict__ out, int B, int HW) {
+    const int C = C0 + C1, CQ = C >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * HW * CQ) return;
+    const int q = (int)(idx % CQ);
+    const size_t pix = idx / CQ;                       // b * HW + p
+    const int b = (int)(pix / HW);
+    const int c = q * 4;
+    const f32x4 x = (c < C0) ? *reinterpret_cast<const f32x4*>(src0 + pix * C0 + c)
+                             : *reinterpret_cast<const f32x4*>(src1 + pix * C1 + (c - C0));
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (size_t)b * C + c) * 16.0f;
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (size_t)b * C + c) * 16.0f;
+    f32x4 v = x * sc + sh;
+    if (silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / 16.0f)));
+    }
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h = (_Float16)v[e];
+        const _Float16 l = (_Float16)(v[e] - (float)h);
+        w[e] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + pix * C + c) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+hipError_t preact_launch(const float* src0, int C0, const float* src1, int C1, const float* scale, const float* shift,
+                         int silu, unsigned* out, int B, int HW, hipStream_t s) {
+    if (C0 % 4 || C1 % 4) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * HW * ((C0 + C1) / 4);
+    hipLaunchKernelGGL(preact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       src0, C0, src1, C1, scale, shift, silu, out, B, HW);
+    return hipGetLastError();
+}
+
 hipError_t gn_stats_launch(const GnArgs& a, hipStream_t s) {
     const int C = a.C0 + a.C1;
     if (C % 8 || C / 4 > GN_THREADS) return hipErrorInvalidValue;    // 8 groups, float4 loads

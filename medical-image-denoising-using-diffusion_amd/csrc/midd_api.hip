@@ -61,7 +61,7 @@ struct TensorRef {
     size_t stat_off = (size_t)-1; int stat_rows = 0;       // per-channel partial sums [B][rows][2][C], if produced
 };
 
-enum OpKind { OP_IN_CONV, OP_GN, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_PART };
+enum OpKind { OP_IN_CONV, OP_GN, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_PART, OP_PREACT };
 struct Op {
     OpKind kind;
     // sources / destination (workspace offsets in bytes)
@@ -593,11 +593,25 @@ struct Builder {
         Op o{}; o.kind = OP_CONV; o.out_scale = wscale; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
         if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
+        // Pre-activation pass for small maps (f16x3): every workgroup of a conv transforms (GroupNorm, SiLU, split)
+        // the halo tile it stages -- Cout/48 x 1.4 times per element.  Where the tensors stay in L2 / Infinity Cache
+        // one elementwise kernel does it once and the conv only unpacks (PRO_PRE).  MIDD_PREACT_MAX_HW = largest
+        // H*W it is used for (0 = never).
+        static const long pre_max_hw = getenv("MIDD_PREACT_MAX_HW") ? atol(getenv("MIDD_PREACT_MAX_HW")) : 0;
+        if (gn_op >= 0 && ks == 3 && p->cfg.compute_mode == MI_COMPUTE_F16X3 && (long)s0.H * s0.W <= pre_max_hw) {
+            Op pre{}; pre.kind = OP_PREACT; pre.s0 = s0; if (s1) { pre.s1 = *s1; pre.has_s1 = true; }
+            pre.scale_off = o.scale_off; pre.shift_off = o.shift_off; pre.prologue = prologue;
+            TensorRef t; t.C = s0.C + (s1 ? s1->C : 0); t.H = s0.H; t.W = s0.W;
+            t.off = bump.take((size_t)B * t.H * t.W * t.C * sizeof(float));
+            pre.dst = t;
+            g->ops.push_back(pre);
+            o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE;
+        }
         // Opt-in (MIDD_GN_FUSE=1): measured at B=8, 256x256 the 51 saved launches per iteration are paid back by the
         // longer prologue of every conv workgroup -- neutral unsplit (39.1 vs 39.1 img/s), -3 % with the default
         // two-stream split, where the small finalize kernels already overlap the other half-batch.
         static const bool fuse_gn = getenv("MIDD_GN_FUSE") && atoi(getenv("MIDD_GN_FUSE")) != 0;
-        if (gn_op >= 0 && fuse_gn && p->cfg.compute_mode == MI_COMPUTE_F16X3) {
+        if (gn_op >= 0 && fuse_gn && p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.prologue != PRO_PRE) {
             g->ops[gn_op].fused = true;          // this conv is the GroupNorm's only consumer
             o.gn_op_plus1 = gn_op + 1;
         }
@@ -793,6 +807,7 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             *flops = 0; *bytes = 8.0 * B * (o.s0.stat_rows * o.s0.C + (o.has_s1 ? o.s1.stat_rows * o.s1.C : 0));
             break;
         case OP_CHAN_PART: *name = "midd::chan_partial_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
+        case OP_PREACT: *name = "midd::preact_kernel"; *flops = 0; *bytes = 8.0 * elems(o.dst); break;
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
                 snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d>", o.tile.mt, o.tile.nt);
@@ -862,6 +877,11 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 e = gn_from_partial_launch(a, s);
                 break;
             }
+            case OP_PREACT:
+                e = preact_launch(F(o.s0.off), o.s0.C, o.has_s1 ? F(o.s1.off) : nullptr, o.has_s1 ? o.s1.C : 0,
+                                  F(o.scale_off), F(o.shift_off), o.prologue == PRO_GN_SILU ? 1 : 0,
+                                  reinterpret_cast<unsigned*>(ws + o.dst.off), B, o.s0.H * o.s0.W, s);
+                break;
             case OP_CHAN_PART:
                 e = chan_partial_launch(F(o.s0.off), F(o.s0.stat_off), B, o.s0.H * o.s0.W, o.s0.C, o.s0.stat_rows, s);
                 break;

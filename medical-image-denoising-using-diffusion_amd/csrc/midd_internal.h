@@ -8,7 +8,9 @@
 namespace midd {
 
 // ---------------------------------------------------------------- implicit-GEMM convolution
-enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
+// PRO_PRE (f16x3 only): the input tensor already holds the MFMA operand, one 32-bit word per element =
+// fp16 hi | fp16 lo << 16 of 2^s * act(GroupNorm(x)) (preact_kernel); the conv only unpacks it.
+enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_PRE = 3 };
 
 struct ConvArgs {
     const float* src0;      // NHWC, C0 channels
@@ -105,6 +107,11 @@ hipError_t gn_from_partial_launch(const GnFromPartialArgs& a, hipStream_t s);
 // per-channel partial sums of an NHWC tensor -> [B][rows][2][C]
 hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
+
+// GroupNorm-apply (+SiLU) + 2^s prescale + fp16 hi/lo split of a (virtually concatenated) NHWC tensor into packed
+// words [B][HW][C0+C1] for PRO_PRE convolutions (groupnorm.hip)
+hipError_t preact_launch(const float* src0, int C0, const float* src1, int C1, const float* scale, const float* shift,
+                         int silu, unsigned* out, int B, int HW, hipStream_t s);
 
 // ---------------------------------------------------------------- pre/post-processing (prepost.hip)
 size_t resize_workspace_bytes(int n, int sw, int sh, int dw, int dh);
