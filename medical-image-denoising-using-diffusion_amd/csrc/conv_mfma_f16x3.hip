@@ -88,7 +88,7 @@ struct Conv16Geom {
 // Diagnostic build only (-DMIDD_CONV_TIMING, tools/conv_timing.py): s_memtime stamps of wave 0 of every
 // workgroup, summed per launch shape.  Shares, not run times: the stamps drain the LDS queue.
 #ifdef MIDD_CONV_TIMING
-enum { TS_WAIT, TS_ISSUE, TS_MFMA, TS_CHUNK_WAIT, TS_TRANSFORM, TS_EPILOGUE, TS_PROLOGUE, TS_FIRSTWAIT, TS_TOTAL, TS_REAL, TS_WGS, TS_N };
+enum { TS_WAIT, TS_ISSUE, TS_MFMA, TS_CHUNK_WAIT, TS_TRANSFORM, TS_EPILOGUE, TS_PROLOGUE, TS_FIRSTWAIT, TS_DMAWAIT, TS_TOTAL, TS_REAL, TS_WGS, TS_N };
 __device__ unsigned long long g_conv_timing[64][TS_N];
 __device__ __forceinline__ unsigned long long ts_stamp() {
     unsigned long long t;
@@ -380,6 +380,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
         }
+        TS(TS_DMAWAIT)                     // diagnostic build: the counted wait alone, then the barrier (TS_WAIT)
         if constexpr (WM != 1) {           // WM == 1: own weights only, no cross-wave hand-off per step
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -553,12 +554,12 @@ extern "C" __attribute__((visibility("default"))) void mi_debug_conv_timing_dump
     static unsigned long long h[64][TS_N];
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_timing), sizeof h);
-    static const char* names[] = {"wait+bar", "dma-issue", "frag+mfma", "chunk-wait", "transform", "epilogue", "prologue", "wait-after-epi"};
+    static const char* names[] = {"barrier", "dma-issue", "frag+mfma", "chunk-wait", "transform", "epilogue", "prologue", "wait-after-epi", "dma-wait"};
     for (size_t i = 0; i < g_timing_names.size(); ++i) {
         const double tot = (double)h[i][TS_TOTAL], wgs = (double)h[i][TS_WGS];
         if (wgs == 0) continue;
         printf("%-70s cyc/wg %9.0f clk %.2f GHz |", g_timing_names[i].c_str(), tot / wgs, tot / (double)h[i][TS_REAL] * 0.1);
-        for (int k = 0; k < 8; ++k) printf(" %s %4.1f%%", names[k], 100.0 * (double)h[i][k] / tot);
+        for (int k = 0; k < 9; ++k) printf(" %s %4.1f%%", names[k], 100.0 * (double)h[i][k] / tot);
         printf("\n");
     }
     memset(h, 0, sizeof h);
