@@ -707,6 +707,7 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
 
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
+    if (a.prologue == PRO_PRE_DMA) return conv3x3_pre_launch(a, t, s);
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
         if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \

@@ -265,7 +265,7 @@ hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int
 // v = x * (16 sc) + 16 sh, SiLU on the 16x-scaled value, hi = fp16(v), lo = fp16(v - hi).
 __global__ __launch_bounds__(256)
 void preact_kernel(const float* __restrict__ src0, int C0, const float* __restrict__ src1, int C1,
-                   const float* __restrict__ scale, const float* __restrict__ shift, int silu,
+                   const float* __restrict__ scale, const float* __restrict__ shift, int silu, int planar,
                    unsigned* __restrict__ out, int B, int HW) {
     const int C = C0 + C1, CQ = C >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -284,22 +284,29 @@ void preact_kernel(const float* __restrict__ src0, int C0, const float* __restri
         for (int e = 0; e < 4; ++e)
             v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / 16.0f)));
     }
-    unsigned w[4];
+    unsigned short hb[4], lb[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const _Float16 h = (_Float16)v[e];
         const _Float16 l = (_Float16)(v[e] - (float)h);
-        w[e] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+        hb[e] = __builtin_bit_cast(unsigned short, h); lb[e] = __builtin_bit_cast(unsigned short, l);
     }
-    *reinterpret_cast<uint4*>(out + pix * C + c) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (planar) {       // per pixel and 16-channel block: 16 high halves (32 B), then 16 low halves (PRO_PRE_DMA)
+        char* o = reinterpret_cast<char*>(out) + (pix * (C >> 4) + (c >> 4)) * 64 + (c & 15) * 2;
+        *reinterpret_cast<uint2*>(o) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+        *reinterpret_cast<uint2*>(o + 32) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+    } else {            // one word per element: hi | lo << 16 (PRO_PRE)
+        *reinterpret_cast<uint4*>(out + pix * C + c) = make_uint4(hb[0] | ((unsigned)lb[0] << 16), hb[1] | ((unsigned)lb[1] << 16),
+                                                                 hb[2] | ((unsigned)lb[2] << 16), hb[3] | ((unsigned)lb[3] << 16));
+    }
 }
 
 hipError_t preact_launch(const float* src0, int C0, const float* src1, int C1, const float* scale, const float* shift,
-                         int silu, unsigned* out, int B, int HW, hipStream_t s) {
-    if (C0 % 4 || C1 % 4) return hipErrorInvalidValue;
+                         int silu, int planar, unsigned* out, int B, int HW, hipStream_t s) {
+    if (C0 % 4 || C1 % 4 || (planar && (C0 + C1) % 16)) return hipErrorInvalidValue;
     const size_t total = (size_t)B * HW * ((C0 + C1) / 4);
     hipLaunchKernelGGL(preact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       src0, C0, src1, C1, scale, shift, silu, out, B, HW);
+                       src0, C0, src1, C1, scale, shift, silu, planar, out, B, HW);
     return hipGetLastError();
 }
 

@@ -79,6 +79,7 @@ struct Op {
     float out_scale = 1.f;
     int gn_op_plus1 = 0;        // OP_CONV (f16x3): index + 1 of the GroupNorm op finalized inside this conv's prologue
     bool fused = false;         // OP_GN: no launch of its own (see gn_op_plus1)
+    bool planar = false;        // OP_PREACT: planar hi/lo blocks (PRO_PRE_DMA) instead of packed words (PRO_PRE)
 };
 
 struct Program {
@@ -620,6 +621,19 @@ struct Builder {
                             ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
                             : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
+        // Pre-activated, DMA-only activation staging (conv3x3_pre_f16x3.hip) for 3x3 stride-1 convs behind a GroupNorm
+        // on maps of at most MIDD_PREDMA_MAX_HW pixels (0 = never), where the picked tile has that kernel.
+        static const long predma_max_hw = getenv("MIDD_PREDMA_MAX_HW") ? atol(getenv("MIDD_PREDMA_MAX_HW")) : 0;
+        if (gn_op >= 0 && ks == 3 && stride == 1 && p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.prologue != PRO_PRE &&
+            !o.gn_op_plus1 && (long)s0.H * s0.W <= predma_max_hw && conv3x3_pre_supports(o.tile) && dst.C % 48 == 0) {
+            Op pre{}; pre.kind = OP_PREACT; pre.s0 = s0; if (s1) { pre.s1 = *s1; pre.has_s1 = true; }
+            pre.scale_off = o.scale_off; pre.shift_off = o.shift_off; pre.prologue = prologue; pre.planar = true;
+            TensorRef t; t.C = s0.C + (s1 ? s1->C : 0); t.H = s0.H; t.W = s0.W;
+            t.off = bump.take((size_t)B * t.H * t.W * t.C * sizeof(float));
+            pre.dst = t;
+            g->ops.push_back(pre);
+            o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE_DMA;
+        }
         if (want_stats) {
             dst.stat_rows = conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C, g->persist_wgs);
             dst.stat_off = bump.take((size_t)B * dst.stat_rows * 2 * dst.C * sizeof(float));
@@ -879,7 +893,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             }
             case OP_PREACT:
                 e = preact_launch(F(o.s0.off), o.s0.C, o.has_s1 ? F(o.s1.off) : nullptr, o.has_s1 ? o.s1.C : 0,
-                                  F(o.scale_off), F(o.shift_off), o.prologue == PRO_GN_SILU ? 1 : 0,
+                                  F(o.scale_off), F(o.shift_off), o.prologue == PRO_GN_SILU ? 1 : 0, o.planar ? 1 : 0,
                                   reinterpret_cast<unsigned*>(ws + o.dst.off), B, o.s0.H * o.s0.W, s);
                 break;
             case OP_CHAN_PART:

@@ -10,7 +10,9 @@ namespace midd {
 // ---------------------------------------------------------------- implicit-GEMM convolution
 // PRO_PRE (f16x3 only): the input tensor already holds the MFMA operand, one 32-bit word per element =
 // fp16 hi | fp16 lo << 16 of 2^s * act(GroupNorm(x)) (preact_kernel); the conv only unpacks it.
-enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_PRE = 3 };
+// PRO_PRE_DMA (f16x3, conv3x3_pre_f16x3.hip): the input is planar per 16-channel block -- 16 fp16 high halves then
+// 16 low halves per pixel (preact_launch with planar = 1) -- i.e. already the MFMA image; staging is LDS-DMA only.
+enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_PRE = 3, PRO_PRE_DMA = 4 };
 
 struct ConvArgs {
     const float* src0;      // NHWC, C0 channels
@@ -111,7 +113,9 @@ int chan_partial_rows(int HW, int C);
 // GroupNorm-apply (+SiLU) + 2^s prescale + fp16 hi/lo split of a (virtually concatenated) NHWC tensor into packed
 // words [B][HW][C0+C1] for PRO_PRE convolutions (groupnorm.hip)
 hipError_t preact_launch(const float* src0, int C0, const float* src1, int C1, const float* scale, const float* shift,
-                         int silu, unsigned* out, int B, int HW, hipStream_t s);
+                         int silu, int planar, unsigned* out, int B, int HW, hipStream_t s);
+bool conv3x3_pre_supports(const ConvTile& t);
+hipError_t conv3x3_pre_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 
 // ---------------------------------------------------------------- pre/post-processing (prepost.hip)
 size_t resize_workspace_bytes(int n, int sw, int sh, int dw, int dh);
