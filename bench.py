@@ -4,8 +4,9 @@
 Contract (task statement): ``python bench.py --gpus N --steps K --warmup W`` — one "step" is one
 pass of the hot path over one batch: ``DiffusionDenoiser.denoise`` of B images through the
 50-iteration reverse loop (BASELINE.json configs[1]: batch 8, 256x256, 50 steps, one MI355X).
-For N > 1 it is launched by torch.distributed.run, one rank per GPU; the batch is sharded
-(B per GPU fixed -> weak scaling) and one RCCL all-gather collects the outputs.
+For N > 1 it runs one rank per GPU (launched by torch.distributed.run; started bare, it launches those
+ranks itself as a child process); the batch is sharded (B per GPU fixed -> weak scaling) and one RCCL
+all-gather collects the outputs.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -24,6 +25,7 @@ import midd_loader  # noqa: E402
 
 midd_loader.load()
 from midd_amd import UNetDiffusion, DiffusionDenoiser, UNetConfig, topology, timestep_list  # noqa: E402
+from midd_amd.native import kernel_source_hash  # noqa: E402
 from midd_amd.sharding import gather_outputs  # noqa: E402
 from midd_amd.weights import make_state_dict, synthetic_xray  # noqa: E402
 
@@ -36,45 +38,92 @@ PEAK_HBM = 8.0e12
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes
-    (profiles/*_pmc_traffic.json, newest: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950
-    corrections applied as MI355X_MICROARCH.md prescribes), or None."""
+    """(HBM bytes per launch of `kernel_name`, provenance) from the committed rocprofv3 --pmc passes
+    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 corrections applied as
+    MI355X_MICROARCH.md prescribes; tools/profile_round.sh).  A profile taken from other kernel sources than the
+    ones this library was built from is refused: (None, reason)."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not found:
-        return None
-    path = found[-1]                      # newest round's passes (tools/profile_round.sh)
+        return None, "no profiles/*_pmc_traffic.json"
+    path = found[-1]                      # newest round's passes
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel_name)
-        return k["hbm_bytes_per_launch"] if k else None
-    except (OSError, ValueError, KeyError):
-        return None
+            doc = json.load(f)
+        if doc.get("kernel_source_hash") != kernel_source_hash():
+            return None, f"{os.path.basename(path)} was taken from other kernel sources (stale): not used"
+        k = doc["kernels"].get(kernel_name)
+        return (k["hbm_bytes_per_launch"] if k else None), os.path.basename(path)
+    except (OSError, ValueError, KeyError) as exc:
+        return None, f"{os.path.basename(path)}: {exc}"
 
 
-def cpu_baseline(sd_np, cfg, size, noise_steps, iters):
-    """The oracle (a port of the reference's CPU path, pinned against it in the build container)
-    timed on this host's cores on a bounded sample: 1 image, `iters` of the 50 iterations."""
+def cpu_baseline(sd_np, cfg, size, noise_steps, iters, batch):
+    """The oracle (a port of the reference's CPU path, pinned against it in the build container) timed on this
+    host's cores on a bounded sample (B = 1 and the workload's batch, 3 repetitions, median):
+    `iters` of the iterations for one image, one iteration for the batch."""
     from oracle import ddim_oracle as orc
     sd = orc.to_torch(sd_np)
     topo = topology(cfg)
-    noisy = torch.from_numpy(synthetic_xray(1, size, size, seed=1234))
     beta, alpha, alpha_hat = orc.schedule(noise_steps)
-    steps = timestep_list(noise_steps, noise_steps)[:iters]
-    x = noisy.clone()
-    with torch.no_grad():
-        orc.unet_forward(sd, topo, x, noisy, torch.tensor([steps[0]]))      # warm-up (thread pool, oneDNN primitives)
+    all_steps = timestep_list(noise_steps, noise_steps)
+
+    def run(noisy, steps):
+        x = noisy.clone()
         t0 = time.perf_counter()
         for i in steps:
-            t = torch.full((1,), i, dtype=torch.long)
+            t = torch.full((noisy.shape[0],), i, dtype=torch.long)
             eps = torch.clamp(orc.unet_forward(sd, topo, x, noisy, t), -5, 5)
             a, ah = alpha[t][:, None, None, None], alpha_hat[t][:, None, None, None]
             x = torch.clamp((1 / torch.sqrt(a)) * (x - ((1 - a) / torch.sqrt(1 - ah)) * eps), 0, 1)
-        dt = time.perf_counter() - t0
-    per_iter = dt / len(steps)
-    return x, steps, dict(value=1.0 / (per_iter * noise_steps), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                          sample=f"1 image {size}x{size}, {len(steps)} of {noise_steps} iterations in {dt:.1f} s, "
-                                 f"torch {torch.__version__} CPU fp32 oracle (oracle/ddim_oracle.py)")
+        return x, time.perf_counter() - t0
+
+    reps = 3
+    with torch.no_grad():
+        one = torch.from_numpy(synthetic_xray(1, size, size, seed=1234))
+        orc.unet_forward(sd, topo, one, one, torch.tensor([all_steps[0]]))      # warm-up (thread pool, oneDNN primitives)
+        steps1 = all_steps[:iters]
+        t1 = []
+        for _ in range(reps):
+            x1, dt = run(one, steps1)
+            t1.append(dt / len(steps1))
+        many = torch.from_numpy(synthetic_xray(batch, size, size, seed=1234))
+        tb = []
+        if batch > 1:
+            run(many, all_steps[:1])
+            for _ in range(reps):
+                tb.append(run(many, all_steps[:1])[1])
+    per_iter_1 = float(np.median(t1))
+    rate_1 = 1.0 / (per_iter_1 * noise_steps)
+    rate_b = batch / (float(np.median(tb)) * noise_steps) if tb else rate_1
+    base = dict(value=rate_b, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"batch {batch} {size}x{size}: 1 of {noise_steps} iterations x {reps} repetitions (median {np.median(tb) if tb else per_iter_1:.2f} s); "
+                       f"batch 1: {len(steps1)} iterations x {reps} repetitions (median {per_iter_1:.2f} s per iteration); "
+                       f"torch {torch.__version__} CPU fp32 oracle (oracle/ddim_oracle.py), value = the batch-{batch} rate",
+                value_batch1=rate_1, reps=reps)
+    return x1, steps1, base
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N fresh ranks with torch.distributed.run
+    as a CHILD process (this process has not touched the GPU and never will), relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        raise SystemExit(proc.returncode or 1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
 
 
 def main():
@@ -86,7 +135,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--noise-steps", type=int, default=50)
-    ap.add_argument("--cpu-iters", type=int, default=10, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=5, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--compute", default=None, choices=["f16x3", "f32"],
                     help="MFMA arithmetic: split-fp16 x3 (default) or fp32-input MFMA")
     args = ap.parse_args()
@@ -94,9 +143,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                   # before anything initialises the GPU in this process
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the sampler path has no CPU fallback")
@@ -170,10 +219,12 @@ def main():
             peak, peak_note = PEAK_MFMA_F16 / 3, "2.5 PFLOP/s dense fp16 MFMA / 3 split passes"
         else:
             peak, peak_note = PEAK_MFMA_F32, "fp32-input MFMA dense peak"
-        traffic = pmc_traffic(dom["name"]) if (Bp == 8 and S == 256) else None
+        traffic, traffic_src = pmc_traffic(dom["name"]) if (Bp == 8 and S == 256) else (None, "profiled for the default workload only")
         result["roofline"] = {
             "bound": "mfma", "kernel": dom["name"], "achieved": achieved / 1e12, "peak": peak / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "peak_note": peak_note,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "peak_note": peak_note,
+            "measured_under": "HIP events around each launch on the stream it goes to; the batch runs as two half-batch "
+                              "programs on two streams, so another kernel is usually co-resident during a span",
             "launches": dom["launches"], "avg_launch_us": 1e3 * dom["total_ms"] / dom["launches"],
             "alg_flops_per_launch": dom["flops"] / dom["launches"],
             "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
@@ -197,8 +248,18 @@ def main():
             key=lambda d: -d["ms"])[:24]
 
         # ---- CPU baseline (rank 0, N = 1 only) + a parity spot check on the same sample ----
+        if world == 1:
+            # serving regime (run.py:107 denoises one image per request): latency of a single image
+            one = torch.from_numpy(synthetic_xray(1, S, S, seed=1234)).to(dev)
+            den.denoise(one, inference_steps=args.inference_steps)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                den.denoise(one, inference_steps=args.inference_steps)
+            torch.cuda.synchronize()
+            result["latency_batch1"] = {"ms_per_image": 1e3 * (time.perf_counter() - t1) / 3, "iterations": n_iters, "image": [S, S]}
         if world == 1 and args.cpu_iters > 0 and S <= 512:
-            x_cpu, steps, base = cpu_baseline(sd_np, cfg, S, args.noise_steps, args.cpu_iters)
+            x_cpu, steps, base = cpu_baseline(sd_np, cfg, S, args.noise_steps, args.cpu_iters, Bp)
             result["cpu_baseline"] = base
             one = torch.from_numpy(synthetic_xray(1, S, S, seed=1234)).to(dev)
             x_gpu = model.run_sampler(one, steps, den.beta, den.alpha, den.alpha_hat, clamp_eps=True)

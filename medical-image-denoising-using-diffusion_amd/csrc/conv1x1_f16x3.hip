@@ -157,7 +157,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     auto compute = [&](f32x4 (&r)[MT][2], bool more) {
         const int ch = c_step * 32 + kq * 8;
         const bool valid = ch < Cin;
-        f32x4 sc0 = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sc1 = sc0;
+        f32x4 sc0 = {RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE}, sc1 = sc0;     // raw operands: unscaled (see conv_mfma_f16x3.hip)
         f32x4 sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
         if (a.prologue != PRO_RAW && valid) {
             sc0 = *reinterpret_cast<const f32x4*>(gnp + ch);       sc1 = *reinterpret_cast<const f32x4*>(gnp + ch + 4);

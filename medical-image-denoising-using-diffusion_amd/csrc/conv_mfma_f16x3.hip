@@ -235,7 +235,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             }
             return;
         }
-        f32x4 sc = {ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE, ACT_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
+        // raw operands (stride-2, folded ConvT, res_conv: not bounded by a GroupNorm) are split unscaled, so the
+        // whole fp16 range (|x| < 65504) is available to them; normalised ones carry 2^s = 16
+        f32x4 sc = {RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
         if (a.prologue != PRO_RAW) {
             sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
             sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch) * ACT_PRESCALE;

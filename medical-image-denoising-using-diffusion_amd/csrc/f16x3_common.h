@@ -8,7 +8,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr float ACT_PRESCALE = 16.0f;             // 2^s, s = 4 (see header); must match midd_api.hip
+constexpr float ACT_PRESCALE = 16.0f;             // 2^s, s = 4, of GroupNorm-ed operands (see header); must match midd_api.hip
+constexpr float RAW_PRESCALE = 1.0f;              // operands no GroupNorm bounds keep fp16's full range: |x| < 65504
 
 __device__ __forceinline__ float silu16(float v) {
     // x * 1/(1+2^(-x*log2 e)) on v_exp_f32 / v_rcp_f32 (~1 ulp each)

@@ -547,6 +547,12 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
     std::vector<float> table = build_time_table(plan, time_rows);
 
     HIPCHK(hipGetDevice(&plan->device));
+    // Programs cache per-layer values derived from the weights (Op::out_scale = 2^-k of the f16x3 packing) and
+    // captured graphs hold wdev/ttab pointers: both are rebuilt after every (re)finalize.  hipFree below
+    // synchronises the device, so nothing that still reads the old buffers is in flight.
+    plan->programs.clear();
+    for (auto& ge : plan->graphs) (void)hipGraphExecDestroy(ge.exec);
+    plan->graphs.clear();
     if (plan->wdev) { HIPCHK(hipFree(plan->wdev)); plan->wdev = nullptr; }
     if (plan->ttab) { HIPCHK(hipFree(plan->ttab)); plan->ttab = nullptr; }
     HIPCHK(hipMalloc((void**)&plan->wdev, pk.buf.size() * sizeof(float)));
@@ -591,7 +597,9 @@ struct Builder {
     }
     int conv(const TensorRef& s0, const TensorRef* s1, TensorRef& dst, size_t w, size_t b, float wscale, int ks, int stride,
              int prologue, int gn_op, int temb_col, const TensorRef* resid, bool want_stats) {
-        Op o{}; o.kind = OP_CONV; o.out_scale = wscale; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
+        Op o{}; o.kind = OP_CONV; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
+        // wscale = 2^-k / 2^s undoes the weight and the activation prescale; raw operands are not prescaled
+        o.out_scale = (prologue == PRO_RAW && p->cfg.compute_mode == MI_COMPUTE_F16X3) ? wscale * ACT_PRESCALE_H : wscale;
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
         if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
         // Pre-activation pass for small maps (f16x3): every workgroup of a conv transforms (GroupNorm, SiLU, split)
@@ -1107,27 +1115,38 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         const size_t part = img_elems / parts;
         HIPCHK(hipEventRecord(plan->sev_fork, s));
         for (int h = 1; h < parts; ++h) HIPCHK(hipStreamWaitEvent(plan->sstream[h], plan->sev_fork, 0));
-        for (int i = 0; i < n_iters; ++i) {
-            const int t = t_list[i];
-            for (int h = 0; h < parts; ++h) {
-                hipStream_t sh = h ? plan->sstream[h] : s;
-                char* wsh = ws + (size_t)h * gh->bytes;
-                HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(wsh + gh->trow_off), t, B / parts, sh));
-                StepIO io{};
-                io.x = x_out + h * part; io.cond = noisy + h * part; io.eps_out = nullptr; io.x_update = x_out + h * part;
-                coef(t, &io.c1, &io.c2, &io.c3);
-                io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems + h * part : nullptr;
-                io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
-                if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
-                hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
-                if ((rc = run_program(plan, gh, io, wsh, sh, mid, parts))) return rc;
+        // From here on the side streams may hold work on x_out and the workspace: whatever happens in the loop,
+        // the caller's stream waits for them before this call returns (the caller frees / reuses both).
+        auto enqueue_all = [&]() -> int {
+            for (int i = 0; i < n_iters; ++i) {
+                const int t = t_list[i];
+                for (int h = 0; h < parts; ++h) {
+                    hipStream_t sh = h ? plan->sstream[h] : s;
+                    char* wsh = ws + (size_t)h * gh->bytes;
+                    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(wsh + gh->trow_off), t, B / parts, sh));
+                    StepIO io{};
+                    io.x = x_out + h * part; io.cond = noisy + h * part; io.eps_out = nullptr; io.x_update = x_out + h * part;
+                    coef(t, &io.c1, &io.c2, &io.c3);
+                    io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems + h * part : nullptr;
+                    io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
+                    if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
+                    hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
+                    int rc2 = run_program(plan, gh, io, wsh, sh, mid, parts);
+                    if (rc2) return rc2;
+                }
+            }
+            return MI_OK;
+        };
+        rc = enqueue_all();
+        for (int h = 1; h < parts; ++h) {
+            const hipError_t e1 = hipEventRecord(plan->sev_join[h], plan->sstream[h]);
+            const hipError_t e2 = (e1 == hipSuccess) ? hipStreamWaitEvent(s, plan->sev_join[h], 0) : e1;
+            if (e2 != hipSuccess) {                                   // cannot order the streams: drain the side stream
+                (void)hipStreamSynchronize(plan->sstream[h]);
+                if (rc == MI_OK) rc = fail(MI_EHIP, "joining side stream %d failed: %s", h, hipGetErrorString(e2));
             }
         }
-        for (int h = 1; h < parts; ++h) {
-            HIPCHK(hipEventRecord(plan->sev_join[h], plan->sstream[h]));
-            HIPCHK(hipStreamWaitEvent(s, plan->sev_join[h], 0));
-        }
-        return MI_OK;
+        return rc;
     }
     for (int i = 0; i < n_iters; ++i) {
         const int t = t_list[i];

@@ -76,7 +76,7 @@ class UNetDiffusion(nn.Module):
         self._stamp = None
         self._time_rows = DEFAULT_TIME_ROWS
         self._lock = threading.RLock()
-        self._workspaces: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        self._workspaces: Dict[Tuple[int, int, int, int, int], torch.Tensor] = {}
 
     # ------------------------------------------------------------------ native plumbing
     @property
@@ -133,15 +133,24 @@ class UNetDiffusion(nn.Module):
         self._workspaces.clear()
         return self._plan
 
+    MAX_WORKSPACES = 4       # resident (shape, stream) workspaces; least recently used is dropped first
+
     def _workspace(self, B: int, H: int, W: int, dev: torch.device) -> torch.Tensor:
-        key = (B, H, W, dev.index)
-        ws = self._workspaces.get(key)
+        """Scratch for one call.  Keyed by the CURRENT STREAM as well as the shape: the library call only
+        enqueues work, so two threads that run the same model on different streams (run.py:85-91 runs the
+        models of one request concurrently) must not share activations; calls on one stream are ordered by
+        the stream itself.  Allocated while that stream is current, so the caching allocator ties the block
+        to it."""
+        key = (B, H, W, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspaces.pop(key, None)
         if ws is None:
             nbytes = native.lib().mi_workspace_bytes(self._plan, B, H, W)
             if nbytes == 0:
                 native.check(-1)
+            while len(self._workspaces) >= self.MAX_WORKSPACES:
+                self._workspaces.pop(next(iter(self._workspaces)))
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-            self._workspaces = {key: ws}          # keep one shape resident
+        self._workspaces[key] = ws                # most recently used last
         return ws
 
     @staticmethod

@@ -102,3 +102,14 @@ def lib() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         raise MiddError(rc, lib().mi_last_error().decode("utf-8", "replace"))
+
+
+def kernel_source_hash() -> str:
+    """sha256 over csrc/: identifies the kernel sources a profile (profiles/*_pmc_traffic.json) was taken from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h*"))):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]

@@ -12,7 +12,7 @@ import types
 REFERENCE_DIR = "/root/reference/Backend"
 
 
-def import_reference():
+def _stub_modules():
     os.environ.setdefault("MPLBACKEND", "Agg")
     sys.dont_write_bytecode = True          # the reference tree is read-only
     for name in ("torchvision", "torchvision.transforms", "torchvision.models",
@@ -26,6 +26,18 @@ def import_reference():
     sys.modules["skimage.metrics"].structural_similarity = lambda *a, **k: None
     if REFERENCE_DIR not in sys.path:
         sys.path.insert(0, REFERENCE_DIR)
+
+
+def import_reference():
+    _stub_modules()
     import DDIM.DDIMModel as ddim
     import cddpm.cddpmModels as cddpm
     return types.SimpleNamespace(ddim=ddim, cddpm=cddpm)
+
+
+def import_hybrid():
+    """The hybrid router file with its own copies of UNetDiffusion / DiffusionDenoiser
+    (hybrid/hybrid3diffusionspeed.py:308-418) and HybridDenoisingRouter (:560-628)."""
+    _stub_modules()
+    import hybrid.hybrid3diffusionspeed as hyb
+    return hyb

@@ -1,0 +1,302 @@
+"""Parity edges and BASELINE.json shapes that round 1 left unpinned ("Next round" item 1):
+an ACTIVE +-5 eps clamp, every iteration's eps / x of the recorded samplers, configs[2] (B=32 x 256^2 x 100
+iterations), configs[3]'s shard (B=32 x 256^2 x 50), configs[4]'s shard (B=8 x 512^2 x 50), fp16-range and
+GroupNorm-offset stress, weights reloaded into a live plan, two threads on two streams.
+
+All through the C ABI.  Tolerances as in test_gpu_parity.py (north_star: |delta| < 1e-3 on sampler outputs)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from midd_amd import UNetDiffusion, DiffusionDenoiser, UNetConfig, topology, timestep_list
+from midd_amd.weights import make_state_dict, synthetic_xray
+from oracle import ddim_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+SMALL = dict(model_channels=16, time_emb_dim=64)
+TOL_FINAL, TOL_EPS = 1e-3, 2e-4
+COMPUTE_MODES = ["f16x3", "f32"]
+CLAMP_GAIN = 15.0            # tests/golden/make_golden_r2.py
+
+
+def _model(cfg_kw, sd_np, variant="ddim", compute="f16x3"):
+    m = UNetDiffusion(variant=variant, compute=compute, **cfg_kw)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    return m.to("cuda").eval()
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def _clamp_sd(cfg, seed, perturb):
+    sd = make_state_dict(cfg, seed=seed, perturb_norm=perturb)
+    sd["out_conv.2.weight"] = (sd["out_conv.2.weight"] * CLAMP_GAIN).astype(np.float32)
+    sd["out_conv.2.bias"] = (sd["out_conv.2.bias"] * CLAMP_GAIN).astype(np.float32)
+    return sd
+
+
+def _run_k(model, den, noisy, steps, k, step_noise=None):
+    """x after the first k iterations of the recorded run (same native loop, truncated timestep list)."""
+    sn = step_noise[:k].contiguous() if step_noise is not None else None
+    return model.run_sampler(noisy, steps[:k], den.beta, den.alpha, den.alpha_hat,
+                             clamp_eps=model.variant != "cddpm", step_noise=sn)
+
+
+@pytest.fixture(scope="module", params=COMPUTE_MODES)
+def full_model(request):
+    cfg = UNetConfig()
+    sd = make_state_dict(cfg, seed=42)
+    return cfg, sd, _model({}, sd, compute=request.param)
+
+
+# ------------------------------------------------------------------------------ every iteration of the small runs
+@pytest.mark.parametrize("compute", COMPUTE_MODES)
+@pytest.mark.parametrize("fixture", ["small_ddim", "small_cddpm", "small_ddim_clamp"])
+def test_every_iteration_eps_and_x(fixture, compute):
+    """eps_i = model(x_{i-1}, noisy, t_i) against the reference's recorded (pre-clamp) eps of EVERY iteration, and x
+    after k = 1..n iterations against its recorded x_k -- unsaturated pixels included, unlike the final image
+    (DDIMModel.py:277-284; the clamp fixture has 46 % of |eps| beyond 5, so :278 is live)."""
+    base = np.load(os.path.join(G, "small_ddim.npz" if fixture == "small_ddim_clamp" else f"{fixture}.npz"))
+    g = np.load(os.path.join(G, f"{fixture}.npz"))
+    variant = "cddpm" if "cddpm" in fixture else "ddim"
+    cfg = UNetConfig(variant=variant, **SMALL)
+    sd = _clamp_sd(cfg, 42, True) if fixture.endswith("clamp") else make_state_dict(cfg, seed=42, perturb_norm=True)
+    model = _model(SMALL, sd, variant, compute)
+    den = DiffusionDenoiser(model, noise_steps=50)
+    noisy = torch.from_numpy(base["den_noisy"]).cuda()
+    steps = [int(s) for s in g["den_steps"]]
+    assert steps == timestep_list(50, int(g["den_inference_steps"]))
+    noise = torch.from_numpy(g["den_noise_scaled"]).cuda() if variant == "cddpm" else None
+    eps_ref, x_ref = g["den_eps"], g["den_x"]
+    if fixture.endswith("clamp"):
+        assert (np.abs(eps_ref) > 5).mean() > 0.3
+    worst_eps = worst_x = 0.0
+    for i, t in enumerate(steps):
+        x_prev = noisy if i == 0 else torch.from_numpy(x_ref[i - 1]).cuda()
+        eps = model(x_prev, noisy, torch.full((noisy.shape[0],), t, dtype=torch.long))
+        scale = max(1.0, float(np.abs(eps_ref[i]).max()))
+        worst_eps = max(worst_eps, _maxdiff(eps, eps_ref[i]) / scale)
+        worst_x = max(worst_x, _maxdiff(_run_k(model, den, noisy, steps, i + 1, noise), x_ref[i]))
+    print(f"{fixture} {compute}: worst eps (relative to max|eps|) {worst_eps:.2e}, worst x_k {worst_x:.2e}")
+    assert worst_eps < TOL_EPS and worst_x < TOL_FINAL
+    assert _maxdiff(den.denoise(noisy, inference_steps=int(g["den_inference_steps"]), **({"step_noise": noise} if noise is not None else {})),
+                    g["den_out"]) < TOL_FINAL
+
+
+def test_clamp_active_full_network(full_model):
+    """Full 12.8 M-parameter UNet, 64x64 x 50 iterations with 80 % of raw eps beyond +-5."""
+    cfg, _, ref_model = full_model
+    g = np.load(os.path.join(G, "full_ddim_64_clamp.npz"))
+    model = _model({}, _clamp_sd(cfg, 42, False), compute=ref_model.compute)
+    den = DiffusionDenoiser(model, noise_steps=50)
+    noisy = torch.from_numpy(synthetic_xray(1, 64, 64, seed=1234)).cuda()
+    steps = timestep_list(50, 50)
+    e0 = model(noisy, noisy, torch.tensor([49]))
+    assert float((e0.abs() > 5).float().mean()) > 0.3
+    d = {"eps_first": _maxdiff(e0, g["den_eps_first"]) / float(np.abs(g["den_eps_first"]).max()),
+         "x1": _maxdiff(_run_k(model, den, noisy, steps, 1), g["den_x_after_1"]),
+         "x10": _maxdiff(_run_k(model, den, noisy, steps, 10), g["den_x_after_10"]),
+         "out": _maxdiff(den.denoise(noisy, inference_steps=50), g["den_out"])}
+    x49 = _run_k(model, den, noisy, steps, 49)
+    d["eps_last"] = _maxdiff(model(x49, noisy, torch.tensor([0])), g["den_eps_last"]) / float(np.abs(g["den_eps_last"]).max())
+    print("clamp full 64:", {k: f"{v:.2e}" for k, v in d.items()})
+    assert d["eps_first"] < TOL_EPS and max(d["x1"], d["x10"], d["out"]) < TOL_FINAL and d["eps_last"] < 5 * TOL_EPS
+
+
+def test_256_intermediate_states(full_model):
+    """The 256x256 fixture's intermediate records (round 1 read only den_out and the first eps)."""
+    cfg, sd, model = full_model
+    g = np.load(os.path.join(G, "full_ddim_256.npz"))
+    den = DiffusionDenoiser(model, noise_steps=50)
+    noisy = torch.from_numpy(synthetic_xray(1, 256, 256, seed=1234)).cuda()
+    steps = timestep_list(50, 50)
+    d1 = _maxdiff(_run_k(model, den, noisy, steps, 1), g["den_x_after_1"])
+    d5 = _maxdiff(_run_k(model, den, noisy, steps, 5), g["den_x_after_5"])
+    x49 = _run_k(model, den, noisy, steps, 49)
+    dl = _maxdiff(model(x49, noisy, torch.tensor([0])), g["den_eps_last"])
+    print(f"256^2: x after 1 / 5 iterations {d1:.2e} / {d5:.2e}, eps of the last iteration {dl:.2e}")
+    assert d1 < TOL_FINAL and d5 < TOL_FINAL and dl < 5 * TOL_EPS
+
+
+# ------------------------------------------------------------------------------ BASELINE.json shapes
+def _batch_with(known, slots, B, size, seed0):
+    """B synthetic images with the fixture images placed at `slots`."""
+    x = synthetic_xray(B, size, size, seed=seed0)
+    for img, s in zip(known, slots):
+        x[s] = img
+    return torch.from_numpy(x).cuda()
+
+
+def test_config3_b32_256_100_iterations(full_model):
+    """configs[2]: batch 32, 256x256, noise_steps = inference_steps = 100; the two reference images sit at slots 5
+    and 27, the other 30 rows are covered by determinism + slot-permutation equivariance (bit for bit)."""
+    cfg, sd, model = full_model
+    g = np.load(os.path.join(G, "full_ddim_256_n100.npz"))
+    known = synthetic_xray(2, 256, 256, seed=int(g["seed_image"]))
+    den = DiffusionDenoiser(model, noise_steps=100)
+    noisy = _batch_with(known, (5, 27), 32, 256, seed0=9000)
+    out = den.denoise(noisy, inference_steps=100)
+    d = max(_maxdiff(out[5], g["den_out"][0]), _maxdiff(out[27], g["den_out"][1]))
+    print(f"config 3 (B=32, 256^2, 100 iterations, {model.compute}): max|d| = {d:.2e}")
+    assert d < TOL_FINAL
+    assert float(out.min()) >= 0 and float(out.max()) <= 1 and torch.isfinite(out).all()
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
+    assert torch.equal(den.denoise(noisy[perm], inference_steps=100), out[perm])
+    # unsaturated intermediate states of the reference images
+    steps = timestep_list(100, 100)
+    x50 = _run_k(model, den, noisy, steps, 50)
+    assert max(_maxdiff(x50[5], g["den_x_after_50"][0]), _maxdiff(x50[27], g["den_x_after_50"][1])) < TOL_FINAL
+
+
+def test_config4_shard_b32_256_50_iterations(full_model):
+    """configs[3]'s per-GPU shard: batch 32, 256x256, 50 iterations; reference image at slot 17."""
+    cfg, sd, model = full_model
+    g = np.load(os.path.join(G, "full_ddim_256.npz"))
+    known = synthetic_xray(1, 256, 256, seed=1234)
+    den = DiffusionDenoiser(model, noise_steps=50)
+    noisy = _batch_with(known, (17,), 32, 256, seed0=9100)
+    out = den.denoise(noisy, inference_steps=50)
+    d = _maxdiff(out[17], g["den_out"][0])
+    print(f"config 4 shard (B=32, 256^2, 50 iterations, {model.compute}): max|d| = {d:.2e}")
+    assert d < TOL_FINAL
+    assert torch.equal(den.denoise(noisy, inference_steps=50), out)
+
+
+def test_config5_shard_b8_512_50_iterations(full_model):
+    """configs[4]'s per-GPU shard: batch 8, 512x512 (N = 4096 attention), 50 iterations; reference image at slot 3."""
+    cfg, sd, model = full_model
+    g = np.load(os.path.join(G, "full_ddim_512.npz"))
+    known = synthetic_xray(1, 512, 512, seed=int(g["seed_image"]))
+    den = DiffusionDenoiser(model, noise_steps=50)
+    noisy = _batch_with(known, (3,), 8, 512, seed0=9200)
+    e0 = model(noisy, noisy, torch.full((8,), 49, dtype=torch.long))
+    out = den.denoise(noisy, inference_steps=50)
+    steps = timestep_list(50, 50)
+    x25 = _run_k(model, den, noisy, steps, 25)
+    d = {"eps_first": _maxdiff(e0[3], g["den_eps_first"][0]), "x25": _maxdiff(x25[3], g["den_x_after_25"][0]),
+         "out": _maxdiff(out[3], g["den_out"][0])}
+    print(f"config 5 shard (B=8, 512^2, 50 iterations, {model.compute}):", {k: f"{v:.2e}" for k, v in d.items()})
+    assert d["eps_first"] < TOL_EPS and d["x25"] < TOL_FINAL and d["out"] < TOL_FINAL
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device="cuda")
+    assert torch.equal(den.denoise(noisy[perm], inference_steps=50), out[perm])
+
+
+# ------------------------------------------------------------------------------ numerical range
+def _traced(sd, cfg, x, cond, t):
+    cap = {}
+    with torch.no_grad():
+        eps = orc.unet_forward(orc.to_torch(sd), topology(cfg), x, cond, t, trace=lambda n, v: cap.__setitem__(n, v.numpy().copy()))
+    return eps.numpy(), cap
+
+
+@pytest.mark.parametrize("compute", COMPUTE_MODES)
+@pytest.mark.parametrize("case", ["magnitude_1e3", "magnitude_2e4", "dc_offset_100"])
+def test_range_stress_vs_oracle(case, compute):
+    """What GroupNorm does not bound: raw (un-normalised) operands of the stride-2, res_conv and residual paths, and
+    a GroupNorm input with |mean| / std = 100.  The split-fp16 operands are 2^s * x with fp16's 65504 ceiling
+    (DESIGN.md section 4); the fused statistics are sums / sums of squares.  Per-layer errors are measured relative to
+    each layer's largest value."""
+    kw = dict(model_channels=32, channel_mult=(1, 2, 2), num_res_blocks=1, attention_resolutions=(2,), time_emb_dim=32)
+    cfg = UNetConfig(**kw)
+    sd = make_state_dict(cfg, seed=77, perturb_norm=True)
+    if case.startswith("magnitude"):
+        gain = 1e3 if case.endswith("1e3") else 2e4
+        sd["in_conv.weight"] = (sd["in_conv.weight"] * gain).astype(np.float32)     # residual stream, skips, down convs ~ gain
+        sd["in_conv.bias"] = (sd["in_conv.bias"] * gain).astype(np.float32)
+    else:
+        sd["in_conv.weight"] = (sd["in_conv.weight"] * 0.7).astype(np.float32)
+        sd["in_conv.bias"] = (50.0 + 0 * sd["in_conv.bias"]).astype(np.float32)      # mean 50, std ~0.5 per channel
+    B, H, W = 2, 32, 32
+    x = torch.from_numpy(synthetic_xray(B, H, W, seed=1, kind="uniform"))
+    cond = torch.from_numpy(synthetic_xray(B, H, W, seed=2))
+    t = torch.tensor([3, 40])
+    ref_eps, cap = _traced(sd, cfg, x, cond, t)
+    m = _model(kw, sd, compute=compute)
+    eps = m(x.cuda(), cond.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert torch.isfinite(eps).all(), "fp16 operand overflow"
+    rel = {}
+    for name, want in cap.items():
+        if name in ("time_mlp", "out_conv"):
+            continue
+        try:
+            got = m.debug_fetch(name, B, H, W).cpu().numpy()
+        except Exception:
+            continue
+        rel[name] = _maxdiff(got, want) / max(1.0, float(np.abs(want).max()))
+    worst = max(rel, key=rel.get)
+    stat = float(np.abs(cap["in_conv"]).max()), float(np.abs(cap["in_conv"].mean()) / cap["in_conv"].std())
+    d = _maxdiff(eps, ref_eps) / max(1.0, float(np.abs(ref_eps).max()))
+    print(f"range {case} {compute}: max|in_conv| {stat[0]:.3g}, |mean|/std {stat[1]:.1f}; worst layer {worst} {rel[worst]:.2e}; eps {d:.2e}")
+    assert rel[worst] < TOL_EPS and d < TOL_EPS
+
+
+# ------------------------------------------------------------------------------ live plan, new weights
+@pytest.mark.parametrize("compute", COMPUTE_MODES)
+def test_reloading_weights_into_a_live_plan(compute):
+    """load_state_dict after a first call: the f16x3 per-layer weight scales (2^-k from max|w|) are part of the cached
+    execution program, which mi_unet_finalize must rebuild."""
+    cfg = UNetConfig(**SMALL)
+    sd_a = make_state_dict(cfg, seed=21, perturb_norm=True)
+    sd_b = make_state_dict(cfg, seed=22, perturb_norm=True)
+    for k in sd_b:                                            # max|w| differs by 8x and 1/8x, layer by layer
+        if k.endswith(".weight") and sd_b[k].ndim == 4:
+            sd_b[k] = (sd_b[k] * (8.0 if sum(k.encode()) % 2 else 0.125)).astype(np.float32)
+    model = _model(SMALL, sd_a, compute=compute)
+    x = torch.from_numpy(synthetic_xray(2, 32, 32, seed=8, kind="uniform"))
+    c = torch.from_numpy(synthetic_xray(2, 32, 32, seed=9))
+    t = torch.tensor([7, 33])
+    den = DiffusionDenoiser(model, noise_steps=50)
+    for sd in (sd_a, sd_b, sd_a):
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        with torch.no_grad():
+            want = orc.unet_forward(orc.to_torch(sd), topology(cfg), x, c, t)
+        got = model(x.cuda(), c.cuda(), t.cuda())
+        assert _maxdiff(got, want) < TOL_EPS * max(1.0, float(want.abs().max()))
+        ref = orc.denoise(orc.to_torch(sd), topology(cfg), c, noise_steps=50, inference_steps=4)
+        assert _maxdiff(den.denoise(c.cuda(), inference_steps=4), ref) < TOL_FINAL
+
+
+# ------------------------------------------------------------------------------ threads
+def test_two_threads_two_streams_share_one_model():
+    """run.py:85-91 runs the models of a request in worker threads; two threads calling denoise on the SAME model from
+    different torch streams must get the serial results (per-stream workspaces, plan-level locks)."""
+    cfg = UNetConfig()
+    model = _model({}, make_state_dict(cfg, seed=42))
+    den = DiffusionDenoiser(model, noise_steps=50)
+    inputs = [torch.from_numpy(synthetic_xray(4, 64, 64, seed=100 + 10 * i)).cuda() for i in range(2)]
+    serial = [den.denoise(x, inference_steps=8).clone() for x in inputs]
+    torch.cuda.synchronize()
+    results = [[None] * 6, [None] * 6]
+    errors = []
+    barrier = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                barrier.wait()
+                for r in range(6):                                   # interleaved enqueues, no syncs in between
+                    results[i][r] = den.denoise(inputs[i], inference_steps=8)
+                stream.synchronize()
+        except Exception as exc:                                     # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        for r in range(6):
+            assert torch.equal(results[i][r], serial[i]), (i, r)
