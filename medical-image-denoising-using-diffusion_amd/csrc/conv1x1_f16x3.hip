@@ -14,6 +14,7 @@
 // Epilogue and contract are those of conv_mfma_f16x3.hip (bias / time embedding / residual, GroupNorm partial
 // sums of the output per (workgroup, wave) row).  Weight pack: pack_conv_f16x3 (midd_api.hip), 32 channels per step.
 #include "f16x3_common.h"
+#include "stats_common.h"
 #include <cstdlib>
 
 namespace midd {
@@ -25,7 +26,12 @@ struct Conv1Geom {
     static constexpr int WSTEP = NT * 2048;                  // bytes of one K-step's weights (hi + lo, NT cout tiles)
     static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
     static constexpr int ADD_FLOATS = NT * 16;
-    static int lds_bytes(int cin) { return ((cin + 31) / 32) * WSTEP + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
+    // the weight image doubles as the scratch of the statistics fold at the end
+    __host__ __device__ static int weight_bytes(int cin) {
+        const int w = ((cin + 31) / 32) * WSTEP, f = stats_scratch_doubles(NTHREADS) * 8;
+        return w < f ? f : w;
+    }
+    static int lds_bytes(int cin) { return weight_bytes(cin) + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
 };
 
 template <int MT, int NT>
@@ -52,7 +58,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     const int ntile_wg = blockIdx.y * NT;
 
     char* const wl = lds;                                                        // [step][NT][hi|lo][lane] x 16 B
-    float* const stat_lds = reinterpret_cast<float*>(wl + nsteps * WSTEP);       // [wave][2][NT*16]
+    float* const stat_lds = reinterpret_cast<float*>(wl + G::weight_bytes(Cin));  // [wave][2][NT*16]
     float* const add_lds = stat_lds + G::STAT_FLOATS;                            // [NT*16]
     float* const gnp = add_lds + G::ADD_FLOATS;                                  // [2][Cin] scale, shift
 
@@ -89,14 +95,8 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             dma16(wbase + step * wstep_bytes + r * 1024, wl + piece * 1024);
         }
     }
-    if (a.prologue != PRO_RAW && a.gn_part0 != nullptr) {
-        gn_finalize_lds(a, b, gnp, ACT_PRESCALE, tid, G::NTHREADS);
-    } else if (a.prologue != PRO_RAW) {
-        for (int i = tid; i < Cin; i += G::NTHREADS) {
-            gnp[i] = a.gn_scale[(size_t)b * Cin + i] * ACT_PRESCALE;     // the prescale is folded into the affine (exact)
-            gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i] * ACT_PRESCALE;
-        }
-    }
+    if (a.prologue != PRO_RAW)            // GroupNorm scale / shift of this sample, the 2^s prescale folded in (exact)
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
     for (int i = tid; i < G::STAT_FLOATS; i += G::NTHREADS) stat_lds[i] = 0.f;
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
@@ -224,8 +224,12 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
-            a.stat_partial[((size_t)(b * a.stat_rows + first_tile) * 2 + which) * a.Cout + ntile_wg * 16 + c] = t;
+            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + first_tile) * 2 + which) * a.Cout + ntile_wg * 16 + c], t);
         }
+        // the weight image is idle now: fold scratch (lds_bytes() reserves at least that much)
+        stats_arrive_and_fold<G::NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, ntile_wg * 16,
+                                           NT * 16, a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
+                                           a.wgs_per_img, reinterpret_cast<double*>(wl));
     }
 }
 

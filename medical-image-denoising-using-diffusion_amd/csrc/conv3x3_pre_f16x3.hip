@@ -15,6 +15,7 @@
 // c+1, which waits for all but the (D-1) youngest weight groups, has it landed; in steps 1..D of chunk c it is
 // younger than the group waited for and is added to the count.
 #include "f16x3_common.h"
+#include "stats_common.h"
 #include <cstdlib>
 
 namespace midd {
@@ -277,8 +278,12 @@ void conv3x3_pre_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < NW; ++m) t += stat_lds[m * ROWF + i];
-            a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + ntile_wg * 16 + c] = t;
+            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + ntile_wg * 16 + c], t);
         }
+        static_assert(2 * G::IMG_BYTES >= stats_scratch_doubles(NTHREADS) * 8, "fold scratch");
+        stats_arrive_and_fold<NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, ntile_wg * 16,
+                                        NT * 16, a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
+                                        a.wgs_per_img, reinterpret_cast<double*>(img0));
     }
 }
 

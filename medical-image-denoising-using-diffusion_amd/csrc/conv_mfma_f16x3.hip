@@ -27,6 +27,7 @@
 // K walk: 32 input channels (two 16-channel blocks) per step and tap; a trailing single block
 // (Cin = 48, 144) pairs two TAPS per step instead.
 #include "f16x3_common.h"
+#include "stats_common.h"
 #include <cstdlib>
 #include <type_traits>
 #ifdef MIDD_CONV_TIMING
@@ -216,25 +217,6 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         if (blk >= nblk) return;
         const int ch = (blk << 4) + (q8 & 3) * 4;
         // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
-        if (a.prologue == PRO_PRE) {        // operand words (hi | lo << 16) made by preact_kernel: unpack only
-            char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
-#pragma unroll
-            for (int s = 0; s < APW; ++s) {
-                const int slot = tid + s * NTHREADS;
-                if (g_off[s] > -2) {
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                    u32x4 w = *reinterpret_cast<const u32x4*>(raw + slot * 16);
-                    if (g_off[s] < 0) w = (u32x4){0u, 0u, 0u, 0u};
-                    const u32x2 hi = {__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u)};
-                    const u32x2 lo = {__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u)};
-                    const int pix = slot / QPP;
-                    *reinterpret_cast<u32x2*>(base + pix * 32) = hi;
-                    *reinterpret_cast<u32x2*>(base + PLANE + pix * 32) = lo;
-                }
-            }
-            return;
-        }
         // raw operands (stride-2, folded ConvT, res_conv: not bounded by a GroupNorm) are split unscaled, so the
         // whole fp16 range (|x| < 65504) is available to them; normalised ones carry 2^s = 16
         f32x4 sc = {RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -304,16 +286,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     issue_a(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
-    if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU) {
-        if (a.gn_part0 != nullptr) {
-            gn_finalize_lds(a, b, gnp, 1.0f, tid, NTHREADS);
-        } else {
-            for (int i = tid; i < Cin; i += NTHREADS) {
-                gnp[i] = a.gn_scale[(size_t)b * Cin + i];
-                gnp[Cin + i] = a.gn_shift[(size_t)b * Cin + i];
-            }
-        }
-    }
+    if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
     for (int i = tid; i < G::STAT_FLOATS; i += NTHREADS) stat_lds[i] = 0.f;
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
@@ -439,7 +413,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             }
         }
     };
-    // one row per workgroup: the waves' LDS rows are folded over wm in a fixed order after a barrier
+    // one row per workgroup: the waves' LDS rows are folded over wm in a fixed order after a barrier and stored
+    // write-through; the last workgroup of this (sample, cout slice) folds the slice's rows into the channel totals
     auto publish_stats = [&]() {
         if (a.stat_partial == nullptr) return;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -453,8 +428,12 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
-            a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + (ntile_wg + wn_i * NT) * 16 + c] = t;
+            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + (ntile_wg + wn_i * NT) * 16 + c], t);
         }
+        static_assert(G::RAW_BYTES + G::IMG_BYTES + RING * WSLICE >= stats_scratch_doubles(NTHREADS) * 8, "fold scratch (raw buffer, image and weight ring: all idle here)");
+        stats_arrive_and_fold<NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, ntile_wg * 16,
+                                        WN * NT * 16, a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
+                                        a.wgs_per_img, reinterpret_cast<double*>(raw));
     };
 
     // ---- tile / chunk loop -----------------------------------------------------------------------
@@ -620,7 +599,7 @@ int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, i
     const int bm = t.wm * t.mt * 16, th = bm / t.tw;
     const int tiles = ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th);
     if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16), persist_wgs);   // one row per workgroup
-    return tiles * t.wm;
+    return tiles;                                            // fp32 kernel: one row per tile
 }
 
 #define MIDD_CONV16_TILES(X)                  \

@@ -23,6 +23,7 @@
 // global loads are in flight while the current chunk's 9*4*MT*NT MFMAs run.  Weights are
 // L2-resident (<= 2.6 MB per layer) and go straight to registers, one tap ahead.
 #include "midd_internal.h"
+#include "stats_common.h"
 
 namespace midd {
 
@@ -49,6 +50,8 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     static_assert(NTHREADS % 4 == 0, "quad id must be thread-constant");
 
     __shared__ f32x4 lds[2][NSLOT];
+    __shared__ double fold_scratch[NTHREADS * 4];          // statistics: wave rows, then the last arriver's fold
+    extern __shared__ float gnp[];                         // [2][Cin] GroupNorm scale, shift of this sample
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,8 +106,8 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             stage[s] = v;
         }
         if (a.prologue != PRO_RAW) {
-            sc = *reinterpret_cast<const f32x4*>(a.gn_scale + (size_t)b * Cin + ch + q * 4);
-            sh = *reinterpret_cast<const f32x4*>(a.gn_shift + (size_t)b * Cin + ch + q * 4);
+            sc = *reinterpret_cast<const f32x4*>(gnp + ch + q * 4);
+            sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch + q * 4);
         }
     };
     auto stage_store = [&](int buf) {
@@ -148,6 +151,10 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) wcur[nt] = wp[nt * 64];
 
+    if (a.prologue != PRO_RAW) {
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
+        __syncthreads();
+    }
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -211,8 +218,11 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
         }
     }
     if (a.stat_partial != nullptr) {
-        // per-channel partial sums of the output for the next GroupNorm (see conv_mfma_f16x3.hip)
-        const int row = trem * WM + wm;
+        // per-channel partial sums of the output for the next GroupNorm: the 16 pixel lanes are folded with
+        // fixed-order shuffles, the WM wave rows through LDS, ONE row per tile is stored write-through and the last
+        // tile of this (sample, cout slice) folds the slice's rows into the channel totals (stats_common.h)
+        float* const wrow = reinterpret_cast<float*>(fold_scratch);          // [wave][2][NT*16]
+        constexpr int ROWF = 2 * NT * 16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -223,12 +233,23 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
                 ssum[nt][e] = s1; ssq[nt][e] = s2;
             }
             if (p16 == 0) {
-                const int co = (ntile0 + nt) * 16 + kq * 4;
-                float* pr = a.stat_partial + ((size_t)(b * a.stat_rows + row) * 2) * a.Cout + co;
-                *reinterpret_cast<f32x4*>(pr) = ssum[nt];
-                *reinterpret_cast<f32x4*>(pr + a.Cout) = ssq[nt];
+                *reinterpret_cast<f32x4*>(wrow + wave * ROWF + nt * 16 + kq * 4) = ssum[nt];
+                *reinterpret_cast<f32x4*>(wrow + wave * ROWF + NT * 16 + nt * 16 + kq * 4) = ssq[nt];
             }
         }
+        __syncthreads();
+        const int c0 = blockIdx.y * (WN * NT * 16);
+        for (int i = tid; i < WN * ROWF; i += NTHREADS) {
+            const int wn_i = i / ROWF, r = i - wn_i * ROWF;
+            const int which = r / (NT * 16), c = r - which * (NT * 16);
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + r];
+            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + trem) * 2 + which) * a.Cout + c0 + wn_i * NT * 16 + c], t);
+        }
+        stats_arrive_and_fold<NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, c0, WN * NT * 16,
+                                        a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
+                                        tiles_per_img, fold_scratch);
     }
 }
 
@@ -241,7 +262,7 @@ static hipError_t launch_one(const ConvArgs& a0, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + TH - 1) / TH;
     dim3 grid(a.B * a.tiles_x * a.tiles_y, a.Cout / (WN * NT * 16));
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(WM * WN * 64), 2 * (a.C0 + a.C1) * sizeof(float), s, a);
     return hipGetLastError();
 }
 

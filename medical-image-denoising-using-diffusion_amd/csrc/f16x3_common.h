@@ -51,52 +51,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// GroupNorm finalize inside a consumer's prologue (ConvArgs::gn_part0 != nullptr; replaces a launch of
-// gn_from_partial_kernel per GroupNorm): per channel the partial rows of sample b are added in row order in
-// fp64, per group the channel sums in channel order in fp64 -- the same order in every workgroup, so all
-// workgroups of a launch (and every launch) see bit-identical scale/shift.  gnp: LDS [2][Cin] floats + 16
-// (mean, rstd per group); on return gnp[c] = mult * rstd * gamma[c], gnp[Cin + c] = mult * (beta[c] - mean * rstd * gamma[c])
-// -- visible after the caller's next barrier.  Called by all threads of the workgroup.
-__device__ __forceinline__ void gn_finalize_lds(const ConvArgs& a, int b, float* gnp, float mult, int tid, int nthreads) {
-    const int Cin = a.C0 + a.C1;
-    const int cg = Cin / GN_GROUPS_;
-    float* const mr = gnp + 2 * Cin;
-    for (int c = tid; c < Cin; c += nthreads) {
-        const float* p; int rows, Cs;
-        if (c < a.C0) { rows = a.gn_rows0; Cs = a.C0; p = a.gn_part0 + (size_t)b * rows * 2 * Cs + c; }
-        else          { rows = a.gn_rows1; Cs = a.C1; p = a.gn_part1 + (size_t)b * rows * 2 * Cs + (c - a.C0); }
-        double s1 = 0, s2 = 0;
-        int r = 0;
-        for (; r + 8 <= rows; r += 8) {                 // 16 loads in flight; fixed summation order
-            float v1[8], v2[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { v1[u] = p[(size_t)(r + u) * 2 * Cs]; v2[u] = p[(size_t)(r + u) * 2 * Cs + Cs]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
-        }
-        for (; r < rows; ++r) { s1 += (double)p[(size_t)r * 2 * Cs]; s2 += (double)p[(size_t)r * 2 * Cs + Cs]; }
-        gnp[c] = (float)s1; gnp[Cin + c] = (float)s2;
-    }
-    lds_barrier();
-    if (tid < GN_GROUPS_) {
-        double t1 = 0, t2 = 0;
-        for (int i = 0; i < cg; ++i) { t1 += (double)gnp[tid * cg + i]; t2 += (double)gnp[Cin + tid * cg + i]; }
-        const double n = (double)a.gn_hw * cg;
-        const double mean = t1 / n;
-        double var = t2 / n - mean * mean;
-        if (var < 0) var = 0;
-        mr[2 * tid] = (float)mean;
-        mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)a.gn_eps));
-    }
-    lds_barrier();
-    for (int c = tid; c < Cin; c += nthreads) {
-        const int g = c / cg;
-        const float sc = mr[2 * g + 1] * a.gn_gamma[c];
-        gnp[c] = mult * sc;
-        gnp[Cin + c] = mult * (a.gn_beta[c] - mr[2 * g] * sc);
-    }
-}
-
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
                                      (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);

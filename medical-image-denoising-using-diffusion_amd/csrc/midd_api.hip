@@ -58,18 +58,21 @@ struct HostWeight { std::vector<int64_t> shape; std::vector<float> data; bool lo
 
 struct TensorRef {
     size_t off = 0; int C = 0, H = 0, W = 0;
-    size_t stat_off = (size_t)-1; int stat_rows = 0;       // per-channel partial sums [B][rows][2][C], if produced
+    // GroupNorm statistics, if produced: partial rows [B][rows][2][C] fp32 and per-channel totals [B][C][2] fp64
+    size_t stat_off = (size_t)-1, tot_off = (size_t)-1; int stat_rows = 0;
 };
 
-enum OpKind { OP_IN_CONV, OP_GN, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_PART, OP_PREACT };
+struct GnRef { size_t gamma = 0, beta = 0; bool on = false; };        // affine of the GroupNorm in front of a consumer
+
+enum OpKind { OP_IN_CONV, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_TOT, OP_PREACT };
 struct Op {
     OpKind kind;
     // sources / destination (workspace offsets in bytes)
     TensorRef s0, s1, dst, resid;
     bool has_s1 = false, has_resid = false;
-    // OP_GN
-    size_t gamma = 0, beta = 0, scale_off = 0, shift_off = 0, partial_off = 0;
-    int nsplit = 1;
+    GnRef gn;                   // OP_CONV / OP_PREACT / OP_OUT: GroupNorm of (s0, s1) applied while staging
+    size_t partial_off = 0;     // OP_ATTN: pre-split K / V^T scratch
+    int cnt_index = -1;         // producers of statistics: first arrival counter (B * slices of them)
     // OP_CONV
     size_t w = 0, b = 0;
     int prologue = PRO_RAW, temb_col = -1;
@@ -77,9 +80,6 @@ struct Op {
     int stride = 1, ks = 3;
     bool want_stats = false;
     float out_scale = 1.f;
-    int gn_op_plus1 = 0;        // OP_CONV (f16x3): index + 1 of the GroupNorm op finalized inside this conv's prologue
-    bool fused = false;         // OP_GN: no launch of its own (see gn_op_plus1)
-    bool planar = false;        // OP_PREACT: planar hi/lo blocks (PRO_PRE_DMA) instead of packed words (PRO_PRE)
 };
 
 struct Program {
@@ -87,6 +87,7 @@ struct Program {
     int persist_wgs = 0;       // f16x3 convs: persistent-workgroup target of this program (0 = default)
     std::vector<Op> ops;
     size_t bytes = 0, trow_off = 0, sched_off = 0, counter_off = 0;
+    size_t cnt_off = 0; int cnt_slots = 0;      // arrival counters of the statistics hand-off (zeroed once per library call)
     std::map<std::string, TensorRef> outputs;
 };
 
@@ -578,73 +579,47 @@ struct Builder {
         t.off = bump.take((size_t)B * H * W * C * sizeof(float));
         return t;
     }
-    // per-channel partial sums for a tensor no MFMA convolution produced
-    void ensure_stats(TensorRef& t) {
-        if (t.stat_off != (size_t)-1) return;
-        t.stat_rows = chan_partial_rows(t.H * t.W, t.C);
-        t.stat_off = bump.take((size_t)B * t.stat_rows * 2 * t.C * sizeof(float));
-        Op o{}; o.kind = OP_CHAN_PART; o.s0 = t; g->ops.push_back(o);
+    int take_counters(int n) { const int i = g->cnt_slots; g->cnt_slots += n; return i; }
+    void alloc_stats(TensorRef& t, int rows) {
+        t.stat_rows = rows;
+        t.stat_off = bump.take((size_t)B * rows * 2 * t.C * sizeof(float));
+        t.tot_off = bump.take((size_t)B * t.C * 2 * sizeof(double));
     }
-    // GroupNorm scale/shift from the producers' partial sums; returns the op index
-    int gn(const TensorRef& s0, const TensorRef* s1, size_t gamma, size_t beta) {
-        Op o{}; o.kind = OP_GN; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
-        const int C = s0.C + (s1 ? s1->C : 0);
-        o.gamma = gamma; o.beta = beta;
-        o.scale_off = bump.take((size_t)B * C * sizeof(float));
-        o.shift_off = bump.take((size_t)B * C * sizeof(float));
-        g->ops.push_back(o);
-        return (int)g->ops.size() - 1;
+    // per-channel totals for a tensor no MFMA convolution produced
+    void ensure_stats(TensorRef& t) {
+        if (t.tot_off != (size_t)-1) return;
+        alloc_stats(t, chan_partial_rows(t.H * t.W, t.C));
+        Op o{}; o.kind = OP_CHAN_TOT; o.s0 = t; o.cnt_index = take_counters(B); g->ops.push_back(o);
     }
     int conv(const TensorRef& s0, const TensorRef* s1, TensorRef& dst, size_t w, size_t b, float wscale, int ks, int stride,
-             int prologue, int gn_op, int temb_col, const TensorRef* resid, bool want_stats) {
+             int prologue, GnRef gn, int temb_col, const TensorRef* resid, bool want_stats) {
         Op o{}; o.kind = OP_CONV; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
         // wscale = 2^-k / 2^s undoes the weight and the activation prescale; raw operands are not prescaled
         o.out_scale = (prologue == PRO_RAW && p->cfg.compute_mode == MI_COMPUTE_F16X3) ? wscale * ACT_PRESCALE_H : wscale;
-        o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col;
-        if (gn_op >= 0) { o.scale_off = g->ops[gn_op].scale_off; o.shift_off = g->ops[gn_op].shift_off; }
-        // Pre-activation pass for small maps (f16x3): every workgroup of a conv transforms (GroupNorm, SiLU, split)
-        // the halo tile it stages -- Cout/48 x 1.4 times per element.  Where the tensors stay in L2 / Infinity Cache
-        // one elementwise kernel does it once and the conv only unpacks (PRO_PRE).  MIDD_PREACT_MAX_HW = largest
-        // H*W it is used for (0 = never).
-        static const long pre_max_hw = getenv("MIDD_PREACT_MAX_HW") ? atol(getenv("MIDD_PREACT_MAX_HW")) : 0;
-        if (gn_op >= 0 && ks == 3 && p->cfg.compute_mode == MI_COMPUTE_F16X3 && (long)s0.H * s0.W <= pre_max_hw) {
-            Op pre{}; pre.kind = OP_PREACT; pre.s0 = s0; if (s1) { pre.s1 = *s1; pre.has_s1 = true; }
-            pre.scale_off = o.scale_off; pre.shift_off = o.shift_off; pre.prologue = prologue;
-            TensorRef t; t.C = s0.C + (s1 ? s1->C : 0); t.H = s0.H; t.W = s0.W;
-            t.off = bump.take((size_t)B * t.H * t.W * t.C * sizeof(float));
-            pre.dst = t;
-            g->ops.push_back(pre);
-            o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE;
-        }
-        // Opt-in (MIDD_GN_FUSE=1): measured at B=8, 256x256 the 51 saved launches per iteration are paid back by the
-        // longer prologue of every conv workgroup -- neutral unsplit (39.1 vs 39.1 img/s), -3 % with the default
-        // two-stream split, where the small finalize kernels already overlap the other half-batch.
-        static const bool fuse_gn = getenv("MIDD_GN_FUSE") && atoi(getenv("MIDD_GN_FUSE")) != 0;
-        if (gn_op >= 0 && fuse_gn && p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.prologue != PRO_PRE) {
-            g->ops[gn_op].fused = true;          // this conv is the GroupNorm's only consumer
-            o.gn_op_plus1 = gn_op + 1;
-        }
+        o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col; o.gn = gn;
+        if (gn.on && (s0.tot_off == (size_t)-1 || (s1 && s1->tot_off == (size_t)-1)))
+            return fail(MI_EINVAL, "internal: GroupNorm input without statistics");
         if (resid) { o.resid = *resid; o.has_resid = true; }
         const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
                             ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
                             : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
-        // Pre-activated, DMA-only activation staging (conv3x3_pre_f16x3.hip) for 3x3 stride-1 convs behind a GroupNorm
-        // on maps of at most MIDD_PREDMA_MAX_HW pixels (0 = never), where the picked tile has that kernel.
+        // Opt-in: pre-activated, DMA-only activation staging (conv3x3_pre_f16x3.hip) for 3x3 stride-1 convs behind a
+        // GroupNorm on maps of at most MIDD_PREDMA_MAX_HW pixels (0 = never), where the picked tile has that kernel.
         static const long predma_max_hw = getenv("MIDD_PREDMA_MAX_HW") ? atol(getenv("MIDD_PREDMA_MAX_HW")) : 0;
-        if (gn_op >= 0 && ks == 3 && stride == 1 && p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.prologue != PRO_PRE &&
-            !o.gn_op_plus1 && (long)s0.H * s0.W <= predma_max_hw && conv3x3_pre_supports(o.tile) && dst.C % 48 == 0) {
+        if (gn.on && ks == 3 && stride == 1 && p->cfg.compute_mode == MI_COMPUTE_F16X3 &&
+            (long)s0.H * s0.W <= predma_max_hw && conv3x3_pre_supports(o.tile) && dst.C % 48 == 0) {
             Op pre{}; pre.kind = OP_PREACT; pre.s0 = s0; if (s1) { pre.s1 = *s1; pre.has_s1 = true; }
-            pre.scale_off = o.scale_off; pre.shift_off = o.shift_off; pre.prologue = prologue; pre.planar = true;
+            pre.gn = gn; pre.prologue = prologue;
             TensorRef t; t.C = s0.C + (s1 ? s1->C : 0); t.H = s0.H; t.W = s0.W;
             t.off = bump.take((size_t)B * t.H * t.W * t.C * sizeof(float));
             pre.dst = t;
             g->ops.push_back(pre);
-            o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE_DMA;
+            o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE_DMA; o.gn = GnRef{};
         }
         if (want_stats) {
-            dst.stat_rows = conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C, g->persist_wgs);
-            dst.stat_off = bump.take((size_t)B * dst.stat_rows * 2 * dst.C * sizeof(float));
+            alloc_stats(dst, conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C, g->persist_wgs));
+            o.cnt_index = take_counters(B * (dst.C / (o.tile.wn * o.tile.nt * 16)));
             o.want_stats = true;
         }
         o.dst = dst;
@@ -665,16 +640,16 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     g->sched_off = bld.bump.take((size_t)MAX_SCHED * sizeof(StepSched));
     int rc;
 
+    const GnRef no_gn{};
     auto run_rb = [&](const Mod& m, const TensorRef& s0, const TensorRef* s1, TensorRef* out) -> int {
         const int cin = s0.C + (s1 ? s1->C : 0);
         if (cin != m.in_c) return fail(MI_EINVAL, "%s: expected %d input channels, graph provides %d", m.name.c_str(), m.in_c, cin);
-        const int g1 = bld.gn(s0, s1, m.g1, m.be1);
         TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
-        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, g1, m.temb_col, nullptr, true))) return rc;
-        const int g2 = bld.gn(h1, nullptr, m.g2, m.be2);
+        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
+        const GnRef g2{m.g2, m.be2, true};
         TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
         if (m.in_c != m.out_c) {
-            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, -1, -1, nullptr, false))) return rc;   // res_conv(x)
+            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, no_gn, -1, nullptr, false))) return rc;   // res_conv(x)
             const TensorRef acc = o;
             if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &acc, true))) return rc;   // + in place
         } else {
@@ -686,15 +661,14 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     };
     auto run_attn = [&](const Mod& m, const TensorRef& x, TensorRef* out) -> int {
         const int C = x.C;
-        const int gi = bld.gn(x, nullptr, m.g1, m.be1);
         TensorRef qkv = bld.alloc(3 * C, x.H, x.W);
-        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, gi, -1, nullptr, false))) return rc;
+        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, GnRef{m.g1, m.be1, true}, -1, nullptr, false))) return rc;
         TensorRef att = bld.alloc(C, x.H, x.W);
         Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = att;
         o.partial_off = bld.bump.take(attention16_scratch_bytes(B, x.H * x.W, C));      // pre-split K / V^T (f16x3)
         g->ops.push_back(o);
         TensorRef y = bld.alloc(C, x.H, x.W);
-        if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, m.sp, 1, 1, PRO_RAW, -1, -1, &x, true))) return rc;
+        if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, m.sp, 1, 1, PRO_RAW, no_gn, -1, &x, true))) return rc;
         *out = y;
         return MI_OK;
     };
@@ -710,7 +684,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         else if (m.kind == MOD_ATTN) { if ((rc = run_attn(m, h, &o))) return rc; }
         else {
             o = bld.alloc(m.out_c, h.H / 2, h.W / 2);     // 3x3 stride 2 pad 1 on even sizes
-            if ((rc = bld.conv(h, nullptr, o, m.wc, m.bc, m.sc, 3, 2, PRO_RAW, -1, -1, nullptr, true))) return rc;
+            if ((rc = bld.conv(h, nullptr, o, m.wc, m.bc, m.sc, 3, 2, PRO_RAW, no_gn, -1, nullptr, true))) return rc;
         }
         h = o; skips.push_back(h); g->outputs[m.name] = h;       // every down module pushes a skip (DDIMModel.py:232)
     }
@@ -744,7 +718,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
             if (skip.H == h.H && skip.W == h.W) {
                 // ConvTranspose(4,2,1) then bilinear back to the skip's (half) size: one folded 3x3
                 TensorRef o = bld.alloc(pending_up->out_c, h.H, h.W);
-                if ((rc = bld.conv(h, nullptr, o, pending_up->wc, pending_up->bc, pending_up->sc, 3, 1, PRO_RAW, -1, -1, nullptr, true))) return rc;
+                if ((rc = bld.conv(h, nullptr, o, pending_up->wc, pending_up->bc, pending_up->sc, 3, 1, PRO_RAW, no_gn, -1, nullptr, true))) return rc;
                 h = o; pending_up = nullptr;
             } else if ((rc = flush_up())) return rc;
         }
@@ -759,8 +733,9 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     }
     if ((rc = flush_up())) return rc;
     if (h.H != H || h.W != W) return fail(MI_EINVAL, "network output is %dx%d for a %dx%d input", h.H, h.W, H, W);
-    const int go = bld.gn(h, nullptr, p->g_out, p->be_out);
-    { Op o{}; o.kind = OP_OUT; o.s0 = h; o.scale_off = g->ops[go].scale_off; o.shift_off = g->ops[go].shift_off; g->ops.push_back(o); }
+    if (h.tot_off == (size_t)-1) return fail(MI_EINVAL, "internal: network output without statistics");
+    { Op o{}; o.kind = OP_OUT; o.s0 = h; o.gn = GnRef{p->g_out, p->be_out, true}; g->ops.push_back(o); }
+    g->cnt_off = bld.bump.take((size_t)(g->cnt_slots + 4) * sizeof(int));
     g->bytes = (bld.bump.cur + 255) & ~(size_t)255;
     return MI_OK;
 }
@@ -824,15 +799,13 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             *flops = 2.0 * B * g->H * g->W * o.dst.C * 9 * 2 * p->cfg.in_channels;
             *bytes = 4.0 * (2.0 * B * p->cfg.in_channels * g->H * g->W + elems(o.dst));
             break;
-        case OP_GN:
-            *name = "midd::gn_from_partial_kernel";
-            *flops = 0; *bytes = 8.0 * B * (o.s0.stat_rows * o.s0.C + (o.has_s1 ? o.s1.stat_rows * o.s1.C : 0));
-            break;
-        case OP_CHAN_PART: *name = "midd::chan_partial_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
+        case OP_CHAN_TOT: *name = "midd::chan_total_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
         case OP_PREACT: *name = "midd::preact_kernel"; *flops = 0; *bytes = 8.0 * elems(o.dst); break;
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
                 snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d>", o.tile.mt, o.tile.nt);
+            else if (o.prologue == PRO_PRE_DMA)
+                snprintf(buf, sizeof(buf), "midd::conv3x3_pre_f16x3_kernel<%d>", o.tile.mt);
             else
                 snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
                          p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
@@ -870,8 +843,9 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
+    auto D = [&](size_t off) { return reinterpret_cast<double*>(ws + off); };
+    int* const cnt = reinterpret_cast<int*>(ws + g->cnt_off);
     for (const Op& o : g->ops) {
-        if (o.kind == OP_GN && o.fused) continue;              // finalized in its consumer's prologue
         hipError_t e = hipSuccess;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
         if (p->profiling) {
@@ -890,22 +864,19 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), B, p->cfg.in_channels,
                                    g->H, g->W, o.dst.C, s);
                 break;
-            case OP_GN: {
-                GnFromPartialArgs a{};
-                a.part0 = F(o.s0.stat_off); a.rows0 = o.s0.stat_rows; a.C0 = o.s0.C;
-                a.part1 = o.has_s1 ? F(o.s1.stat_off) : nullptr; a.rows1 = o.has_s1 ? o.s1.stat_rows : 0; a.C1 = o.has_s1 ? o.s1.C : 0;
-                a.B = B; a.HW = o.s0.H * o.s0.W; a.gamma = wd + o.gamma; a.beta = wd + o.beta; a.eps = 1e-5f;
-                a.scale = F(o.scale_off); a.shift = F(o.shift_off);
-                e = gn_from_partial_launch(a, s);
+            case OP_PREACT: {
+                PreactArgs a{};
+                a.src0 = F(o.s0.off); a.C0 = o.s0.C; a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
+                a.gn_tot0 = D(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? D(o.s1.tot_off) : nullptr;
+                a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
+                a.silu = o.prologue == PRO_GN_SILU ? 1 : 0; a.out = reinterpret_cast<unsigned*>(ws + o.dst.off);
+                a.B = B; a.HW = o.s0.H * o.s0.W;
+                e = preact_launch(a, s);
                 break;
             }
-            case OP_PREACT:
-                e = preact_launch(F(o.s0.off), o.s0.C, o.has_s1 ? F(o.s1.off) : nullptr, o.has_s1 ? o.s1.C : 0,
-                                  F(o.scale_off), F(o.shift_off), o.prologue == PRO_GN_SILU ? 1 : 0, o.planar ? 1 : 0,
-                                  reinterpret_cast<unsigned*>(ws + o.dst.off), B, o.s0.H * o.s0.W, s);
-                break;
-            case OP_CHAN_PART:
-                e = chan_partial_launch(F(o.s0.off), F(o.s0.stat_off), B, o.s0.H * o.s0.W, o.s0.C, o.s0.stat_rows, s);
+            case OP_CHAN_TOT:
+                e = chan_total_launch(F(o.s0.off), F(o.s0.stat_off), D(o.s0.tot_off), cnt + o.cnt_index, B, o.s0.H * o.s0.W,
+                                      o.s0.C, o.s0.stat_rows, s);
                 break;
             case OP_CONV: {
                 ConvArgs a{};
@@ -914,17 +885,14 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.B = B; a.H = o.s0.H; a.W = o.s0.W; a.OH = o.dst.H; a.OW = o.dst.W;
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue;
-                if (o.prologue != PRO_RAW) { a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off); }
-                if (o.gn_op_plus1) {
-                    const Op& n = g->ops[o.gn_op_plus1 - 1];
-                    a.gn_part0 = F(n.s0.stat_off); a.gn_rows0 = n.s0.stat_rows;
-                    a.gn_part1 = n.has_s1 ? F(n.s1.stat_off) : nullptr; a.gn_rows1 = n.has_s1 ? n.s1.stat_rows : 0;
-                    a.gn_gamma = wd + n.gamma; a.gn_beta = wd + n.beta; a.gn_eps = 1e-5f; a.gn_hw = n.s0.H * n.s0.W;
+                if (o.gn.on) {
+                    a.gn_tot0 = D(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? D(o.s1.tot_off) : nullptr;
+                    a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f; a.gn_hw = o.s0.H * o.s0.W;
                 }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
                 a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;
-                if (o.want_stats) { a.stat_partial = F(o.dst.stat_off); a.stat_rows = o.dst.stat_rows; }
+                if (o.want_stats) { a.stat_partial = F(o.dst.stat_off); a.stat_rows = o.dst.stat_rows; a.stat_tot = D(o.dst.tot_off); a.stat_cnt = cnt + o.cnt_index; }
                 a.persist_wgs = g->persist_wgs;
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
                 break;
@@ -942,7 +910,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 break;
             case OP_OUT: {
                 OutConvArgs a{};
-                a.src = F(o.s0.off); a.gn_scale = F(o.scale_off); a.gn_shift = F(o.shift_off);
+                a.src = F(o.s0.off); a.gn_tot = D(o.s0.tot_off); a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                 a.w = wd + p->w_out; a.bias = wd + p->b_out;
                 a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
                 a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;
@@ -977,6 +945,12 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
     return MI_OK;
 }
 
+// The arrival counters of the statistics hand-off (stats_common.h) start every library call at zero; inside a call the
+// last arriver of each launch resets its counter, so one memset per call (not per launch) is enough.
+static hipError_t reset_counters(const Program* g, char* ws, hipStream_t s) {
+    return hipMemsetAsync(ws + g->cnt_off, 0, (size_t)(g->cnt_slots + 4) * sizeof(int), s);
+}
+
 static int check_call(mi_plan* plan, int B, int H, int W, void* ws, size_t ws_bytes, Program** g) {
     if (!plan) return fail(MI_EINVAL, "null plan");
     int rc = get_program(plan, B, H, W, g);
@@ -1001,6 +975,7 @@ extern "C" int mi_unet_forward(mi_plan* plan, const float* x, const float* condi
     char* ws = (char*)workspace;
     hipError_t e = fill_i32_launch(reinterpret_cast<int*>(ws + g->trow_off), t, B, s);
     if (e != hipSuccess) return fail(MI_EHIP, "fill timesteps: %s", hipGetErrorString(e));
+    HIPCHK(reset_counters(g, ws, s));
     StepIO io{x, condition, eps, nullptr, nullptr, 0.f, 0.f, 0.f, 0};
     return run_program(plan, g, io, ws, s);
 }
@@ -1056,6 +1031,7 @@ static int denoise_graph(mi_plan* plan, Program* g, const float* noisy, float* x
     HIPCHK(hipStreamWaitEvent(gs, plan->gev_in, 0));
     HIPCHK(hipMemcpyAsync(ws + g->sched_off, sched.data(), sched.size() * sizeof(StepSched), hipMemcpyHostToDevice, gs));
     HIPCHK(hipMemsetAsync(ws + g->counter_off, 0, sizeof(int), gs));
+    HIPCHK(reset_counters(g, ws, gs));
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, gs));   // x = noisy_img.clone()
     for (int i = 0; i < n_iters; ++i) HIPCHK(hipGraphLaunch(exec, gs));
     HIPCHK(hipEventRecord(plan->gev_out, gs));
@@ -1118,6 +1094,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         // From here on the side streams may hold work on x_out and the workspace: whatever happens in the loop,
         // the caller's stream waits for them before this call returns (the caller frees / reuses both).
         auto enqueue_all = [&]() -> int {
+            for (int h = 0; h < parts; ++h) HIPCHK(reset_counters(gh, ws + (size_t)h * gh->bytes, h ? plan->sstream[h] : s));
             for (int i = 0; i < n_iters; ++i) {
                 const int t = t_list[i];
                 for (int h = 0; h < parts; ++h) {
@@ -1148,6 +1125,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         }
         return rc;
     }
+    HIPCHK(reset_counters(g, ws, s));
     for (int i = 0; i < n_iters; ++i) {
         const int t = t_list[i];
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ws + g->trow_off), t, B, s));                     // t = full((B,), i)

@@ -8,11 +8,10 @@
 namespace midd {
 
 // ---------------------------------------------------------------- implicit-GEMM convolution
-// PRO_PRE (f16x3 only): the input tensor already holds the MFMA operand, one 32-bit word per element =
-// fp16 hi | fp16 lo << 16 of 2^s * act(GroupNorm(x)) (preact_kernel); the conv only unpacks it.
 // PRO_PRE_DMA (f16x3, conv3x3_pre_f16x3.hip): the input is planar per 16-channel block -- 16 fp16 high halves then
-// 16 low halves per pixel (preact_launch with planar = 1) -- i.e. already the MFMA image; staging is LDS-DMA only.
-enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_PRE = 3, PRO_PRE_DMA = 4 };
+// 16 low halves per pixel of 2^s * act(GroupNorm(x)) (preact_kernel) -- i.e. already the MFMA image; staging is
+// LDS-DMA only.
+enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_PRE_DMA = 4 };
 
 struct ConvArgs {
     const float* src0;      // NHWC, C0 channels
@@ -23,8 +22,11 @@ struct ConvArgs {
     const float* wpack;     // [Cin/16][taps][Cout/16][64 lanes][4]  (MFMA A-fragment order)
     const float* bias;      // [Cout]
     int Cout;
-    const float* gn_scale;  // [B][Cin]  rstd*gamma            (prologue != RAW)
-    const float* gn_shift;  // [B][Cin]  beta - mean*rstd*gamma
+    // GroupNorm of the INPUT (prologue != RAW): per-channel fp64 (sum, sum of squares) totals of the two concatenated
+    // sources, [B][C0][2] / [B][C1][2], written by the producers' last-arriving workgroups (stats_common.h); every
+    // workgroup derives scale = rstd*gamma, shift = beta - mean*rstd*gamma of its sample in its prologue
+    const double* gn_tot0; const double* gn_tot1;
+    const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_hw;      // affine [Cin], eps, pixels per channel
     int prologue;
     const float* temb;      // time table [rows][temb_stride], already offset to this block's column
     int temb_stride;
@@ -33,18 +35,16 @@ struct ConvArgs {
     float* out;             // NHWC [B][OH][OW][Cout]
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     const float* zeros;     // (unused) 64 zero floats
-    // optional fused GroupNorm statistics of the OUTPUT: per (sample, row, channel) partial sum and
-    // sum of squares, layout [B][stat_rows][2][Cout]; row = tile*WM + wave_m (see conv_stat_rows)
+    // optional fused GroupNorm statistics of the OUTPUT: per (sample, row, channel) partial sum and sum of squares,
+    // layout [B][stat_rows][2][Cout], one row per workgroup (f16x3: persistent workgroup; f32: tile); the last
+    // workgroup to arrive at stat_cnt[b * gridDim.y + blockIdx.y] folds its cout slice into stat_tot [B][Cout][2]
     float* stat_partial;
     int stat_rows;
+    double* stat_tot;
+    int* stat_cnt;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
     int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default), must match conv_stat_rows
-    // f16x3 kernels: GroupNorm finalize fused into the prologue.  gn_part0 != nullptr: the workgroup derives
-    // scale/shift of ITS sample from the producers' partial sums [B][rows][2][C] itself (fixed order, so every
-    // workgroup gets identical values) instead of reading gn_scale/gn_shift written by gn_from_partial_kernel.
-    const float* gn_part0; const float* gn_part1; int gn_rows0, gn_rows1;
-    const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_hw;
 #ifdef MIDD_CONV_TIMING
     int dbg_slot;           // diagnostic build: row of g_conv_timing
 #endif
@@ -82,38 +82,21 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
     return full * taps + half * ((taps + 1) / 2);
 }
 
-// ---------------------------------------------------------------- GroupNorm statistics
-struct GnArgs {
-    const float* src0; const float* src1; int C0, C1;
-    int B, HW;
-    const float* gamma; const float* beta;   // [C]
-    float eps;
-    double* partial;        // [B][nsplit][8][2] scratch
-    int nsplit;
-    float* scale; float* shift;              // [B][C] outputs
-};
-hipError_t gn_stats_launch(const GnArgs& a, hipStream_t s);
-int gn_pick_nsplit(int B, int HW, int C);
-
-// GroupNorm from per-channel partial sums (produced by conv epilogues or chan_partial_launch):
-// up to two sources (torch.cat), each [B][rows][2][C].
+// ---------------------------------------------------------------- GroupNorm statistics (stats_common.h)
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
-struct GnFromPartialArgs {
-    const float* part0; int rows0, C0;
-    const float* part1; int rows1, C1;
-    int B; int HW;                              // pixels per sample the sums cover
-    const float* gamma; const float* beta; float eps;
-    float* scale; float* shift;                // [B][C0+C1]
-};
-hipError_t gn_from_partial_launch(const GnFromPartialArgs& a, hipStream_t s);
-// per-channel partial sums of an NHWC tensor -> [B][rows][2][C]
-hipError_t chan_partial_launch(const float* src, float* part, int B, int HW, int C, int rows, hipStream_t s);
+// per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
+// sample write partial rows [B][rows][2][C]; the last one to arrive at cnt[b] folds them into tot [B][C][2]
+hipError_t chan_total_launch(const float* src, float* part, double* tot, int* cnt, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
-// GroupNorm-apply (+SiLU) + 2^s prescale + fp16 hi/lo split of a (virtually concatenated) NHWC tensor into packed
-// words [B][HW][C0+C1] for PRO_PRE convolutions (groupnorm.hip)
-hipError_t preact_launch(const float* src0, int C0, const float* src1, int C1, const float* scale, const float* shift,
-                         int silu, int planar, unsigned* out, int B, int HW, hipStream_t s);
+// GroupNorm-apply (+SiLU) + 2^s prescale + fp16 hi/lo split of a (virtually concatenated) NHWC tensor into the planar
+// operand image of PRO_PRE_DMA convolutions (groupnorm.hip)
+struct PreactArgs {
+    const float* src0; const float* src1; int C0, C1;
+    const double* gn_tot0; const double* gn_tot1; const float* gn_gamma; const float* gn_beta; float gn_eps;
+    int silu; unsigned* out; int B, HW;
+};
+hipError_t preact_launch(const PreactArgs& a, hipStream_t s);
 bool conv3x3_pre_supports(const ConvTile& t);
 hipError_t conv3x3_pre_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 
@@ -140,7 +123,7 @@ hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9
 
 struct OutConvArgs {
     const float* src;       // NHWC [B][H][W][C]
-    const float* gn_scale; const float* gn_shift;   // [B][C]
+    const double* gn_tot; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][2], affine [C]
     const float* w;         // [ic][9][C]
     const float* bias;      // [ic]
     int B, H, W, C, ic;

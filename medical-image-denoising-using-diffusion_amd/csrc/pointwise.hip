@@ -10,6 +10,7 @@
 // K = 18 and N = 1 are degenerate GEMM shapes: these stay on the vector ALU and are judged
 // against the HBM roofline.
 #include "midd_internal.h"
+#include "stats_common.h"
 
 namespace midd {
 
@@ -86,15 +87,18 @@ constexpr int OC_PS = 20;         // padded pixel stride in floats
 __global__ __launch_bounds__(256)
 void out_conv_kernel(const OutConvArgs a) {
     __shared__ float tile[OC_I * OC_I * OC_PS];
-    extern __shared__ float wl[];                 // [ic][9][C]
+    extern __shared__ float wl[];                 // [ic][9][C], then [2][C] GroupNorm scale / shift of this sample
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
+    float* const gnp = wl + a.ic * 9 * a.C;
     const int tiles_x = (a.W + OC_T - 1) / OC_T, tiles_y = (a.H + OC_T - 1) / OC_T;
     const int b = blockIdx.x / (tiles_x * tiles_y);
     const int trem = blockIdx.x - b * tiles_x * tiles_y;
     const int oy0 = (trem / tiles_x) * OC_T, ox0 = (trem % tiles_x) * OC_T;
     const int C = a.C;
     for (int i = tid; i < a.ic * 9 * C; i += 256) wl[i] = a.w[i];
+    // (second source: C1 = 0, never read; a literal nullptr there crashes hipcc 7.2's inliner)
+    gn_prologue_lds(a.gn_tot, C, a.gn_tot, 0, a.gn_gamma, a.gn_beta, a.gn_eps, a.H * a.W, b, 1.0f, gnp, tid, 256);
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};          // ic <= 4 output channels
     for (int c0 = 0; c0 < C; c0 += 16) {
@@ -106,8 +110,8 @@ void out_conv_kernel(const OutConvArgs a) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                 v = *reinterpret_cast<const f32x4*>(a.src + ((size_t)(b * a.H + gy) * a.W + gx) * C + c0 + q * 4);
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(a.gn_scale + (size_t)b * C + c0 + q * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(a.gn_shift + (size_t)b * C + c0 + q * 4);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(gnp + c0 + q * 4);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(gnp + C + c0 + q * 4);
                 v = v * sc + sh;
                 v.x = silu_pw(v.x); v.y = silu_pw(v.y); v.z = silu_pw(v.z); v.w = silu_pw(v.w);
             }
@@ -155,7 +159,7 @@ void out_conv_kernel(const OutConvArgs a) {
 
 hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s) {
     if (a.ic > 4 || a.C % 16) return hipErrorInvalidValue;
-    const size_t lds = (size_t)a.ic * 9 * a.C * sizeof(float);
+    const size_t lds = ((size_t)a.ic * 9 * a.C + 2 * a.C) * sizeof(float);
     const int tiles = ((a.W + OC_T - 1) / OC_T) * ((a.H + OC_T - 1) / OC_T);
     hipLaunchKernelGGL(out_conv_kernel, dim3(a.B * tiles), dim3(256), lds, s, a);
     return hipGetLastError();

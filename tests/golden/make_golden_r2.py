@@ -6,7 +6,8 @@ Kept apart from make_golden.py so the round-1 fixtures are never rewritten.  Wha
 
   clamp   `torch.clamp(predicted_noise, -5, 5)` ACTIVE (DDIMModel.py:278): out_conv.2.weight / .bias scaled x15, so a
           sizeable fraction of |eps| exceeds 5 and the clamped value drives the update (:283-284).  Reduced UNet,
-          every iteration's raw eps and x; full UNet at 64x64 x 50 iterations.
+          every iteration's raw eps and x; full UNet at 64x64, 10 iterations (a horizon over which the reference
+          reproduces itself across thread counts: the x15 loop amplifies rounding differences).
   c3      BASELINE.json configs[2]: noise_steps=100, inference_steps=100 at 256x256 (two images).
   c5      BASELINE.json configs[4]'s per-image shape: 512x512 x 50 iterations (one image; N=4096 attention).
   hybrid  the hybrid file's OWN copies of the classes (hybrid/hybrid3diffusionspeed.py:284-418): un-chunked attention
@@ -67,18 +68,27 @@ def gen_clamp(ref):
     np.savez_compressed(os.path.join(HERE, "small_ddim_clamp.npz"), den_out=xf, den_eps=eps, den_x=np.stack(x_log),
                         den_steps=np.array(timestep_list(50, S), np.int64), den_inference_steps=np.int64(S),
                         gain=np.float32(CLAMP_GAIN), frac_clamped=np.float64(frac))
+    # Full network: 10 iterations.  With the x15 head the loop amplifies rounding differences (the reference's own
+    # 50-iteration output moves by 9e-4 between 4 and 8 CPU threads), so the recorded horizon is kept short enough for
+    # the reference to reproduce itself: checked here.
     cfg = UNetConfig()
     model = build_from(ref.ddim, cfg, clamp_state_dict(cfg, 42, False))
     den = ref.ddim.DiffusionDenoiser(model, noise_steps=50)
     noisy = torch.from_numpy(synthetic_xray(1, 64, 64, seed=1234))
-    xf, eps_log, x_log = traced_denoise(den, noisy, 50)
+    S = 10
+    xf, eps_log, x_log = traced_denoise(den, noisy, S)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(max(1, nthreads // 2))
+    xf2, _, _ = traced_denoise(den, noisy, S)
+    torch.set_num_threads(nthreads)
+    self_diff = float(np.abs(xf - xf2).max())
     eps = np.stack(eps_log)
     frac = float((np.abs(eps) > 5).mean())
-    print(f"clamp full 64: {100 * frac:.1f} % of raw eps beyond +-5")
-    assert frac > 0.05
-    np.savez_compressed(os.path.join(HERE, "full_ddim_64_clamp.npz"), den_out=xf, den_eps_first=eps[0], den_eps_last=eps[-1],
-                        den_x_after_1=x_log[0], den_x_after_10=x_log[9], gain=np.float32(CLAMP_GAIN),
-                        frac_clamped=np.float64(frac))
+    print(f"clamp full 64: {100 * frac:.1f} % of raw eps beyond +-5; reference vs itself at half the threads: {self_diff:.2e}")
+    assert frac > 0.05 and self_diff < 1e-4
+    np.savez_compressed(os.path.join(HERE, "full_ddim_64_clamp.npz"), den_out=xf, den_eps=eps, den_x=np.stack(x_log),
+                        den_steps=np.array(timestep_list(50, S), np.int64), den_inference_steps=np.int64(S),
+                        gain=np.float32(CLAMP_GAIN), frac_clamped=np.float64(frac), reference_self_diff=np.float64(self_diff))
 
 
 def gen_c3(ref):

@@ -92,23 +92,25 @@ def test_every_iteration_eps_and_x(fixture, compute):
 
 
 def test_clamp_active_full_network(full_model):
-    """Full 12.8 M-parameter UNet, 64x64 x 50 iterations with 80 % of raw eps beyond +-5."""
+    """Full 12.8 M-parameter UNet, 64x64, 10 iterations with most raw eps beyond +-5: every iteration's eps and x.
+    (Longer horizons are not a parity target for this fixture: with the x15 head the loop amplifies rounding
+    differences -- the reference's own 50-iteration output moves by 9e-4 between 4 and 8 CPU threads.)"""
     cfg, _, ref_model = full_model
     g = np.load(os.path.join(G, "full_ddim_64_clamp.npz"))
     model = _model({}, _clamp_sd(cfg, 42, False), compute=ref_model.compute)
     den = DiffusionDenoiser(model, noise_steps=50)
     noisy = torch.from_numpy(synthetic_xray(1, 64, 64, seed=1234)).cuda()
-    steps = timestep_list(50, 50)
-    e0 = model(noisy, noisy, torch.tensor([49]))
-    assert float((e0.abs() > 5).float().mean()) > 0.3
-    d = {"eps_first": _maxdiff(e0, g["den_eps_first"]) / float(np.abs(g["den_eps_first"]).max()),
-         "x1": _maxdiff(_run_k(model, den, noisy, steps, 1), g["den_x_after_1"]),
-         "x10": _maxdiff(_run_k(model, den, noisy, steps, 10), g["den_x_after_10"]),
-         "out": _maxdiff(den.denoise(noisy, inference_steps=50), g["den_out"])}
-    x49 = _run_k(model, den, noisy, steps, 49)
-    d["eps_last"] = _maxdiff(model(x49, noisy, torch.tensor([0])), g["den_eps_last"]) / float(np.abs(g["den_eps_last"]).max())
-    print("clamp full 64:", {k: f"{v:.2e}" for k, v in d.items()})
-    assert d["eps_first"] < TOL_EPS and max(d["x1"], d["x10"], d["out"]) < TOL_FINAL and d["eps_last"] < 5 * TOL_EPS
+    steps = [int(s) for s in g["den_steps"]]
+    assert steps == timestep_list(50, int(g["den_inference_steps"])) and (np.abs(g["den_eps"]) > 5).mean() > 0.3
+    worst_eps = worst_x = 0.0
+    for i, t in enumerate(steps):
+        x_prev = noisy if i == 0 else torch.from_numpy(g["den_x"][i - 1]).cuda()
+        eps = model(x_prev, noisy, torch.tensor([t]))
+        worst_eps = max(worst_eps, _maxdiff(eps, g["den_eps"][i]) / float(np.abs(g["den_eps"][i]).max()))
+        worst_x = max(worst_x, _maxdiff(_run_k(model, den, noisy, steps, i + 1), g["den_x"][i]))
+    print(f"clamp full 64 {model.compute}: worst eps (relative) {worst_eps:.2e}, worst x_k {worst_x:.2e}")
+    assert worst_eps < TOL_EPS and worst_x < TOL_FINAL
+    assert _maxdiff(den.denoise(noisy, inference_steps=int(g["den_inference_steps"])), g["den_out"]) < TOL_FINAL
 
 
 def test_256_intermediate_states(full_model):
@@ -300,3 +302,49 @@ def test_two_threads_two_streams_share_one_model():
     for i in range(2):
         for r in range(6):
             assert torch.equal(results[i][r], serial[i]), (i, r)
+
+
+# ------------------------------------------------------------------------------ statistics hand-off inside a launch
+def test_statistics_are_never_stale_across_launches():
+    """The GroupNorm totals are folded by the last-arriving workgroup of the PRODUCING launch from rows other workgroups
+    stored write-through (csrc/stats_common.h).  A stale read of those rows would return the previous launch's values:
+    alternate two very different inputs through the same plan / workspace and require, bit for bit, the results of
+    fresh single runs."""
+    cfg = UNetConfig()
+    sd = make_state_dict(cfg, seed=42)
+    model = _model({}, sd)
+    den = DiffusionDenoiser(model, noise_steps=50)
+    a = torch.from_numpy(synthetic_xray(4, 128, 128, seed=11)).cuda()
+    b = (1.0 - torch.from_numpy(synthetic_xray(4, 128, 128, seed=900, kind="uniform"))).cuda() * 0.3
+    ra = den.denoise(a, inference_steps=3).clone()
+    fresh = _model({}, sd)
+    rb = DiffusionDenoiser(fresh, noise_steps=50).denoise(b, inference_steps=3).clone()
+    ea = model(a, a, torch.full((4,), 20, dtype=torch.long)).clone()
+    for _ in range(3):
+        assert torch.equal(den.denoise(b, inference_steps=3), rb)
+        assert torch.equal(den.denoise(a, inference_steps=3), ra)
+        assert torch.equal(model(a, a, torch.full((4,), 20, dtype=torch.long)), ea)
+
+
+def test_optional_kernels_are_reached():
+    """Child-process helper of test_gpu_optional_paths.py: with an opt-in knob in the environment, the kernel it
+    selects must actually be launched on the shapes that test runs (full network, B = 4, 64x64 and 128x128)."""
+    knobs = {k: os.environ.get(k) for k in ("MIDD_PREDMA_MAX_HW", "MIDD_TILE_BIG", "MIDD_TILE_NT6", "MIDD_CONV1X1_DIRECT")}
+    cfg = UNetConfig()
+    model = _model({}, make_state_dict(cfg, seed=42))
+    names = set()
+    for size in (64, 128):
+        x = torch.from_numpy(synthetic_xray(4, size, size, seed=5)).cuda()
+        model.profile_begin()
+        model(x, x, torch.full((4,), 7, dtype=torch.long))
+        names |= {p["name"] for p in model.profile_end()}
+    print(sorted(names))
+    assert not any("gn_from_partial" in n for n in names), "GroupNorm finalize must not be a launch"
+    if knobs["MIDD_PREDMA_MAX_HW"]:
+        assert any("conv3x3_pre_f16x3_kernel" in n for n in names) and any("preact_kernel" in n for n in names)
+    if knobs["MIDD_TILE_BIG"]:
+        assert any("conv_mfma_f16x3_kernel<3, 1, 16, 4," in n for n in names)
+    if knobs["MIDD_TILE_NT6"]:
+        assert any("conv_mfma_f16x3_kernel<3, 1, 16, 2, 6," in n for n in names)
+    if knobs["MIDD_CONV1X1_DIRECT"] == "0":
+        assert not any("conv1x1_f16x3_kernel" in n for n in names) and any("conv_mfma_f16x3_kernel<1, 1," in n for n in names)
