@@ -4,16 +4,27 @@
 //
 // Replaces AttentionBlock.forward's matmul / softmax / matmul
 // (/root/reference/Backend/DDIM/DDIMModel.py:149-162; heads = 2, head_dim = C/2, q scaled by
-// head_dim^-0.5, full softmax over the keys — the reference's 512-query chunking is exact).
+// head_dim^-0.5, full softmax over the keys — the reference's 512-query chunking is exact; the hybrid
+// copy's un-chunked form with the scale after QK^T, hybrid3diffusionspeed.py:295-301, is the same function).
 //
 //   S^T[key][q] = K . Q^T   A = K rows (16 B = 8 consecutive d per lane), B = Q^T from registers
 //   P           = exp2(S^T - m)  online softmax; the lane that owns a query column owns its m, l
-//   O^T[d][q]  += V^T . P^T  A = V^T (LDS image is transposed while staging), B = P^T straight
-//                            from the score accumulators: the 32-wide k index of this MFMA is
-//                            permuted so that element j of lane group kq is key 16*(j>>2)+4*kq+(j&3)
-//                            of the key pair-block — exactly the keys the lane already holds.
+//   O^T[d][q]  += V^T . P^T  A = V^T (pre-transposed image), B = P^T straight from the score accumulators:
+//                            the 32-wide k index of this MFMA is permuted so that element j of lane group kq
+//                            is key 16*(j>>2)+4*kq+(j&3) of the key pair-block — the keys the lane already holds.
 // Every fp32 operand x is used as x*2^s = hi + lo (fp16 each, exact power-of-two prescale):
 // q,k,v: s = 4; p in [0,1]: s = 10; hi.hi + hi.lo + lo.hi reproduces the fp32 product to ~2^-21.
+//
+// Structure (round 2; the round-1 kernel ran 128 workgroups of 4 x 16 queries on 256 CUs and every one of them
+// re-read the whole K / V image through register-staged copies with two barriers per tile):
+//   * workgroup = 4 waves x 32 queries (two 16-query MFMA column tiles per wave): every K / V^T fragment read
+//     from LDS feeds six MFMAs instead of three;
+//   * the keys are split `ksplit` ways over workgroups (flash-decoding style) so that ~512 workgroups exist at any
+//     batch size; each split leaves (m, l, unnormalised O^T) and attention_combine_kernel merges them in split
+//     order (deterministic);
+//   * K / V^T tiles of 32 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction, per-lane source addresses so the padded, conflict-free LDS rows need no padded global
+//     image) into a two-stage ring: one barrier per tile, the next tile in flight under the MFMAs.
 #include "midd_internal.h"
 #include <cstdlib>
 
@@ -22,9 +33,11 @@ namespace midd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 
-constexpr int A16_KT = 64;                 // keys per LDS tile
+constexpr int A16_KT = 32;                 // keys per LDS tile
+constexpr int A16_QW = 32;                 // queries per wave
+constexpr int A16_QB = 4 * A16_QW;         // queries per workgroup
+constexpr int A16_MAX_SPLIT = 8;
 constexpr float A16_QKV_SCALE = 16.0f;     // 2^4
 constexpr float A16_P_SCALE = 1024.0f;     // 2^10
 
@@ -33,9 +46,14 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+__device__ __forceinline__ void att_dma16(const void* gsrc, char* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
+                                     (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
+}
+
 // Pre-split pass: K and V of every (sample, head) are converted ONCE to the fp16 hi/lo images the
-// attention kernel stages (instead of once per 64-query workgroup):
-//   Kp [B][heads][2 (hi,lo)][N][D]      Vp [B][heads][2][D][Npad]   (V transposed, Npad = N rounded to 64)
+// attention kernel stages (instead of once per query block):
+//   Kp [B][heads][2 (hi,lo)][Npad][D]   Vp [B][heads][2][D][Npad]   (V transposed; Npad = N rounded up to 64; keys >= N are zeros)
 __global__ __launch_bounds__(256)
 void attention_prep_kernel(const float* __restrict__ qkv, _Float16* __restrict__ Kp, _Float16* __restrict__ Vp,
                            int N, int Npad, int C, int D, int heads) {
@@ -43,36 +61,33 @@ void attention_prep_kernel(const float* __restrict__ qkv, _Float16* __restrict__
     const int C3 = 3 * C;
     const float* base = qkv + (size_t)b * N * C3;
     const int kcol = C + head * D, vcol = 2 * C + head * D;
-    _Float16* kh = Kp + ((size_t)(b * heads + head) * 2) * N * D;
-    _Float16* kl = kh + (size_t)N * D;
+    _Float16* kh = Kp + ((size_t)(b * heads + head) * 2) * Npad * D;
+    _Float16* kl = kh + (size_t)Npad * D;
     _Float16* vh = Vp + ((size_t)(b * heads + head) * 2) * D * Npad;
     _Float16* vl = vh + (size_t)D * Npad;
-    const int key0 = blockIdx.x * 64;
-    // K: float4 along d
-    for (int idx = threadIdx.x; idx < 64 * (D / 4); idx += 256) {
-        const int key = key0 + idx / (D / 4), dq = idx % (D / 4);
-        if (key < N) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(base + (size_t)key * C3 + kcol + dq * 4);
-            half4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { _Float16 h_, l_; split1(kv[e] * A16_QKV_SCALE, h_, l_); hi[e] = h_; lo[e] = l_; }
-            *reinterpret_cast<half4*>(kh + (size_t)key * D + dq * 4) = hi;
-            *reinterpret_cast<half4*>(kl + (size_t)key * D + dq * 4) = lo;
-        }
-    }
-    // V^T through an LDS transpose: coalesced float4 reads along d, then each thread writes 8 consecutive
-    // keys (16 bytes) of one d-row per plane; keys >= N are written as zeros
-    __shared__ float vt[64][128 + 1];
-    for (int idx = threadIdx.x; idx < 64 * (D / 4); idx += 256) {
+    const int key0 = blockIdx.x * 32;
+    __shared__ float vt[32][128 + 1];
+    // K: float4 along d; V: staged for the transpose in the same pass
+    for (int idx = threadIdx.x; idx < 32 * (D / 4); idx += 256) {
         const int kk = idx / (D / 4), dq = idx % (D / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (key0 + kk < N) v = *reinterpret_cast<const f32x4*>(base + (size_t)(key0 + kk) * C3 + vcol + dq * 4);
+        const int key = key0 + kk;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+        if (key < N) {
+            kv = *reinterpret_cast<const f32x4*>(base + (size_t)key * C3 + kcol + dq * 4);
+            v = *reinterpret_cast<const f32x4*>(base + (size_t)key * C3 + vcol + dq * 4);
+        }
+        half4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { _Float16 h_, l_; split1(kv[e] * A16_QKV_SCALE, h_, l_); hi[e] = h_; lo[e] = l_; }
+        *reinterpret_cast<half4*>(kh + (size_t)key * D + dq * 4) = hi;
+        *reinterpret_cast<half4*>(kl + (size_t)key * D + dq * 4) = lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) vt[kk][dq * 4 + e] = v[e] * A16_QKV_SCALE;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < D * 8; idx += 256) {
-        const int d = idx >> 3, k8 = idx & 7;
+    // V^T: each thread writes 8 consecutive keys (16 bytes) of one d-row per plane
+    for (int idx = threadIdx.x; idx < D * 4; idx += 256) {
+        const int d = idx >> 2, k8 = idx & 3;
         half8 hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { _Float16 h_, l_; split1(vt[k8 * 8 + j][d], h_, l_); hi[j] = h_; lo[j] = l_; }
@@ -81,36 +96,86 @@ void attention_prep_kernel(const float* __restrict__ qkv, _Float16* __restrict__
     }
 }
 
-template <int D, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64)
+template <int D>
+struct Att16Geom {
+    static constexpr int KCH = D / 8 + 2;                  // 16-byte chunks per K row in LDS: D halfs + 16 pad (224-B rows at D = 96: conflict-free b128 reads)
+    static constexpr int KROW = KCH * 16;                  // bytes
+    static constexpr int VCH = A16_KT / 8 + 1;             // chunks per V^T row: 32 keys + 8 pad (80-B rows: conflict-free b64 reads)
+    static constexpr int VROW = VCH * 16;
+    static constexpr int KCHUNKS = 2 * A16_KT * KCH;       // both planes
+    static constexpr int VCHUNKS = 2 * D * VCH;
+    static constexpr int KPLANE = A16_KT * KROW;           // bytes of one K plane
+    static constexpr int VPLANE = D * VROW;
+    static constexpr int KBYTES = 2 * KPLANE, VBYTES = 2 * VPLANE;
+    static constexpr int PIECES = (KCHUNKS + VCHUNKS) / 64;
+    static constexpr int PPW = (PIECES + 3) / 4;           // per wave
+    static constexpr int STAGE = KBYTES + VBYTES;
+    static_assert(KCHUNKS % 64 == 0 && VCHUNKS % 64 == 0, "a DMA piece must not straddle the K / V images");
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2)
 void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vp,
-                            float* __restrict__ out, int N, int Npad, int C, float qscale) {
+                            float* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml,
+                            int N, int Npad, int C, float qscale, int ksplit, int tiles_per_split) {
+    using G = Att16Geom<D>;
     constexpr int DC = D / 32;                 // 32-wide k chunks of the head dimension (QK^T)
     constexpr int DT = D / 16;                 // 16-row output tiles of O^T
-    constexpr int KLD = D + 16;                // K image row (halfs): [key][d]; 224-B rows make the ds_read_b128 fragment reads conflict-free (D + 8: 2-way)
-    constexpr int VLD = A16_KT + 8;            // V^T image row (halfs): [d][key]
-    constexpr int KB = A16_KT / 16;
-    static_assert(D % 32 == 0, "head_dim must be a multiple of 32");
-    __shared__ __attribute__((aligned(16))) _Float16 Kh[A16_KT * KLD], Kl[A16_KT * KLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Vh[D * VLD], Vl[D * VLD];
+    constexpr int QM = A16_QW / 16;            // 16-query column tiles per wave
+    constexpr int KB = A16_KT / 16;            // 16-key blocks per tile
+    static_assert(D % 32 == 0 && KB == 2, "head_dim must be a multiple of 32; one 32-key pair-block per tile");
+    extern __shared__ __attribute__((aligned(16))) char lds[];            // two stages of [K hi | K lo | V^T hi | V^T lo]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kq = lane >> 4;
     const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-    constexpr int NT_ = NWAVES * 64;           // threads per workgroup; NWAVES*16 queries per workgroup
-    const int q0 = blockIdx.x * (NWAVES * 16) + wave * 16;
+    const int qb = blockIdx.x / ksplit, ks = blockIdx.x - qb * ksplit;
+    const int q0 = qb * A16_QB + wave * A16_QW;
     const int C3 = 3 * C;
     const float* base = qkv + (size_t)b * N * C3;
     const int qcol = head * D;
-    const _Float16* gkh = Kp + ((size_t)(b * heads + head) * 2) * N * D;
-    const _Float16* gkl = gkh + (size_t)N * D;
-    const _Float16* gvh = Vp + ((size_t)(b * heads + head) * 2) * D * Npad;
-    const _Float16* gvl = gvh + (size_t)D * Npad;
+    const char* gk = reinterpret_cast<const char*>(Kp + ((size_t)(b * heads + head) * 2) * Npad * D);
+    const char* gv = reinterpret_cast<const char*>(Vp + ((size_t)(b * heads + head) * 2) * D * Npad);
+    const int ntiles = (N + A16_KT - 1) / A16_KT;
+    const int t_begin = ks * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
-    // Q^T fragments: lane holds Q[q0+l16][32c + 8kq + j] * scale*log2(e) * 2^4, split hi/lo
-    half8 qh[DC], ql[DC];
-    {
-        const int qi = q0 + l16;
+    // ---- DMA plan: piece p (1 KiB of the stage image) = chunks 64p .. 64p+63; this lane's chunk -> global source ----
+    const char* src[G::PPW];
+    int adv[G::PPW];                           // bytes the source moves per tile
+#pragma unroll
+    for (int i = 0; i < G::PPW; ++i) {
+        const int piece = wave + 4 * i;
+        const int c = piece * 64 + lane;
+        const char* s = gk; int a = 0;
+        if (c < G::KCHUNKS) {
+            const int plane = c / (A16_KT * G::KCH), rem = c - plane * (A16_KT * G::KCH);
+            const int key = rem / G::KCH, ch = rem - key * G::KCH;
+            if (ch < D / 8) { s = gk + ((size_t)plane * Npad + key) * (D * 2) + ch * 16; a = A16_KT * D * 2; }
+        } else if (c < G::KCHUNKS + G::VCHUNKS) {
+            const int cv = c - G::KCHUNKS;
+            const int plane = cv / (D * G::VCH), rem = cv - plane * (D * G::VCH);
+            const int d = rem / G::VCH, ch = rem - d * G::VCH;
+            if (ch < A16_KT / 8) { s = gv + ((size_t)plane * D + d) * ((size_t)Npad * 2) + ch * 16; a = A16_KT * 2; }
+        }
+        src[i] = s + (size_t)t_begin * a; adv[i] = a;                     // pad chunks: a valid dummy source, never read back
+    }
+    auto issue = [&](int stage) {
+        char* dst = lds + stage * G::STAGE;
+#pragma unroll
+        for (int i = 0; i < G::PPW; ++i) {
+            const int piece = wave + 4 * i;
+            if (piece < G::PIECES) att_dma16(src[i], dst + piece * 1024);
+            src[i] += adv[i];
+        }
+    };
+    if (t_begin < t_end) issue(0);
+
+    // ---- Q^T fragments: lane holds Q[q0 + 16qm + l16][32c + 8kq + j] * scale*log2(e) * 2^4, split hi/lo ----
+    half8 qh[QM][DC], ql[QM][DC];
+#pragma unroll
+    for (int qm = 0; qm < QM; ++qm) {
+        const int qi = q0 + qm * 16 + l16;
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
 #pragma unroll
@@ -121,177 +186,203 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
                 for (int e = 0; e < 4; ++e) {
                     _Float16 hi, lo;
                     split1(v[e] * (qscale * A16_QKV_SCALE), hi, lo);
-                    qh[c][h * 4 + e] = hi; ql[c][h * 4 + e] = lo;
+                    qh[qm][c][h * 4 + e] = hi; ql[qm][c][h * 4 + e] = lo;
                 }
             }
         }
     }
 
-    f32x4 o[DT];
+    f32x4 o[QM][DT];
 #pragma unroll
-    for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    for (int qm = 0; qm < QM; ++qm)
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[qm][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m[QM], l[QM];
+#pragma unroll
+    for (int qm = 0; qm < QM; ++qm) { m[qm] = -INFINITY; l[qm] = 0.f; }
 
-    // register-staged software pipeline: tile t+1 is fetched (16-byte copies of the pre-split
-    // images) while tile t is being multiplied; it is written to LDS after the barrier that ends t.
-    constexpr int KSL = (A16_KT * (D / 8) + NT_ - 1) / NT_;    // 16-byte K slots per thread and plane
-    constexpr int VSL = (D * (A16_KT / 8) + NT_ - 1) / NT_;
-    half8 pkh[KSL], pkl[KSL], pvh[VSL], pvl[VSL];
-    auto fetch = [&](int kt0) {
-#pragma unroll
-        for (int i = 0; i < KSL; ++i) {
-            const int idx = tid + i * NT_;
-            const int key = idx / (D / 8), d8 = idx - key * (D / 8);
-            half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < A16_KT * (D / 8) && kt0 + key < N) {
-                h = *reinterpret_cast<const half8*>(gkh + (size_t)(kt0 + key) * D + d8 * 8);
-                lo = *reinterpret_cast<const half8*>(gkl + (size_t)(kt0 + key) * D + d8 * 8);
-            }
-            pkh[i] = h; pkl[i] = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < VSL; ++i) {
-            const int idx = tid + i * NT_;
-            const int d = idx / (A16_KT / 8), k8 = idx - d * (A16_KT / 8);
-            half8 h = {0, 0, 0, 0, 0, 0, 0, 0}, lo = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (idx < D * (A16_KT / 8)) {
-                h = *reinterpret_cast<const half8*>(gvh + (size_t)d * Npad + kt0 + k8 * 8);
-                lo = *reinterpret_cast<const half8*>(gvl + (size_t)d * Npad + kt0 + k8 * 8);
-            }
-            pvh[i] = h; pvl[i] = lo;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < KSL; ++i) {
-            const int idx = tid + i * NT_;
-            const int key = idx / (D / 8), d8 = idx - key * (D / 8);
-            if (idx < A16_KT * (D / 8)) {
-                *reinterpret_cast<half8*>(&Kh[key * KLD + d8 * 8]) = pkh[i];
-                *reinterpret_cast<half8*>(&Kl[key * KLD + d8 * 8]) = pkl[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < VSL; ++i) {
-            const int idx = tid + i * NT_;
-            const int d = idx / (A16_KT / 8), k8 = idx - d * (A16_KT / 8);
-            if (idx < D * (A16_KT / 8)) {
-                *reinterpret_cast<half8*>(&Vh[d * VLD + k8 * 8]) = pvh[i];
-                *reinterpret_cast<half8*>(&Vl[d * VLD + k8 * 8]) = pvl[i];
-            }
-        }
-    };
-    fetch(0);
-    for (int kt0 = 0; kt0 < N; kt0 += A16_KT) {
-        __syncthreads();                       // every wave is done reading the previous tile
-        commit();
-        __syncthreads();
-        if (kt0 + A16_KT < N) fetch(kt0 + A16_KT);
+    const int koff = l16 * G::KROW + kq * 16;                 // K fragment: row = key l16 of the block, 8 halfs at d = 32c + 8kq
+    const int voff = l16 * G::VROW + kq * 8;                  // V^T fragment: row = d l16 of the tile, keys 4kq.. and 16+4kq..
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int stage = (t - t_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t have landed (the Q loads too)
+        __builtin_amdgcn_s_barrier();                         // ... everybody's; and everybody is done reading the other stage
+        asm volatile("" ::: "memory");
+        if (t + 1 < t_end) issue(stage ^ 1);
+        const char* Kh = lds + stage * G::STAGE;
+        const char* Vh = Kh + G::KBYTES;
+        const int kt0 = t * A16_KT;
 
         // S^T = K . Q^T (x 2^8): rows = keys, cols = queries
-        f32x4 st[KB];
+        f32x4 st[QM][KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qm = 0; qm < QM; ++qm) st[qm][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
-                const int off = (kb * 16 + l16) * KLD + c * 32 + kq * 8;
-                const half8 kh = *reinterpret_cast<const half8*>(&Kh[off]);
-                const half8 kl = *reinterpret_cast<const half8*>(&Kl[off]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[c], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[c], acc, 0, 0, 0);
+                const int off = kb * 16 * G::KROW + koff + c * 64;
+                const half8 kh = *reinterpret_cast<const half8*>(Kh + off);
+                const half8 kl = *reinterpret_cast<const half8*>(Kh + G::KPLANE + off);
+#pragma unroll
+                for (int qm = 0; qm < QM; ++qm) {
+                    st[qm][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[qm][c], st[qm][kb], 0, 0, 0);
+                    st[qm][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[qm][c], st[qm][kb], 0, 0, 0);
+                    st[qm][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[qm][c], st[qm][kb], 0, 0, 0);
+                }
             }
-            st[kb] = acc * (1.0f / (A16_QKV_SCALE * A16_QKV_SCALE));   // lane: query l16, keys kt0 + 16kb + 4kq + r
         }
 
-        // online softmax (base-2 domain)
-        float tmax = -INFINITY;
+        // online softmax (base-2 domain); lane: query l16 of tile qm, keys kt0 + 16kb + 4kq + r
+        half8 ph[QM], pl[QM];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int qm = 0; qm < QM; ++qm) {
+            float tmax = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (kt0 + kb * 16 + kq * 4 + r >= N) st[kb][r] = -INFINITY;
-                tmax = fmaxf(tmax, st[kb][r]);
+            for (int kb = 0; kb < KB; ++kb) {
+                st[qm][kb] = st[qm][kb] * (1.0f / (A16_QKV_SCALE * A16_QKV_SCALE));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (kt0 + kb * 16 + kq * 4 + r >= N) st[qm][kb][r] = -INFINITY;
+                    tmax = fmaxf(tmax, st[qm][kb][r]);
+                }
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-        float psum = 0.f;
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m[qm], tmax);           // finite: the first key of every tile is < N
+            const float alpha = __builtin_amdgcn_exp2f(m[qm] - m_new);
+            float psum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
-                st[kb][r] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 16);
-        psum += __shfl_xor(psum, 32);
-        l = l * alpha + psum;
-        m = m_new;
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(st[qm][kb][r] - m_new);
+                    psum += p;
+                    _Float16 h_, l_;
+                    split1(p * A16_P_SCALE, h_, l_);
+                    ph[qm][kb * 4 + r] = h_; pl[qm][kb * 4 + r] = l_;
+                }
+            psum += __shfl_xor(psum, 16);
+            psum += __shfl_xor(psum, 32);
+            l[qm] = l[qm] * alpha + psum;
+            m[qm] = m_new;
 #pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] *= alpha;
+            for (int tt = 0; tt < DT; ++tt) o[qm][tt] *= alpha;
+        }
 
-        // O^T += V^T . P^T over key pair-blocks (32 keys per MFMA)
+        // O^T += V^T . P^T over the tile's 32 keys
 #pragma unroll
-        for (int kp = 0; kp < KB / 2; ++kp) {
-            half8 ph, pl;
+        for (int tt = 0; tt < DT; ++tt) {
+            const int off = tt * 16 * G::VROW + voff;
+            half8 vh, vl;
+            const half4 vh0 = *reinterpret_cast<const half4*>(Vh + off), vh1 = *reinterpret_cast<const half4*>(Vh + off + 32);
+            const half4 vl0 = *reinterpret_cast<const half4*>(Vh + G::VPLANE + off), vl1 = *reinterpret_cast<const half4*>(Vh + G::VPLANE + off + 32);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 h_, l_;
-                split1(st[2 * kp + (j >> 2)][j & 3] * A16_P_SCALE, h_, l_);
-                ph[j] = h_; pl[j] = l_;
-            }
+            for (int e = 0; e < 4; ++e) { vh[e] = vh0[e]; vh[4 + e] = vh1[e]; vl[e] = vl0[e]; vl[4 + e] = vl1[e]; }
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                const int off = (t * 16 + l16) * VLD + kp * 32 + kq * 4;
-                half8 vh, vl;
-                const half4 vh0 = *reinterpret_cast<const half4*>(&Vh[off]), vh1 = *reinterpret_cast<const half4*>(&Vh[off + 16]);
-                const half4 vl0 = *reinterpret_cast<const half4*>(&Vl[off]), vl1 = *reinterpret_cast<const half4*>(&Vl[off + 16]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vh[e] = vh0[e]; vh[4 + e] = vh1[e]; vl[e] = vl0[e]; vl[4 + e] = vl1[e]; }
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[t], 0, 0, 0);
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[t], 0, 0, 0);
+            for (int qm = 0; qm < QM; ++qm) {
+                o[qm][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[qm], o[qm][tt], 0, 0, 0);
+                o[qm][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[qm], o[qm][tt], 0, 0, 0);
+                o[qm][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[qm], o[qm][tt], 0, 0, 0);
             }
         }
     }
 
-    // O^T accumulator: col = query l16, row = d = 16t + 4kq + r  ->  out[b][q][head*D + d]
-    const int qi = q0 + l16;
-    if (qi < N) {
-        const float inv = 1.0f / (l * A16_QKV_SCALE * A16_P_SCALE);
-        float* orow = out + ((size_t)b * N + qi) * C + head * D + kq * 4;
+    // O^T accumulator: col = query l16, row = d = 16t + 4kq + r
 #pragma unroll
-        for (int t = 0; t < DT; ++t) *reinterpret_cast<f32x4*>(orow + t * 16) = o[t] * inv;
+    for (int qm = 0; qm < QM; ++qm) {
+        const int qi = q0 + qm * 16 + l16;
+        if (qi >= N) continue;
+        if (ksplit == 1) {
+            const float inv = 1.0f / (l[qm] * A16_QKV_SCALE * A16_P_SCALE);
+            float* orow = out + ((size_t)b * N + qi) * C + head * D + kq * 4;
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt) *reinterpret_cast<f32x4*>(orow + tt * 16) = o[qm][tt] * inv;
+        } else {
+            float* orow = part_o + (((size_t)ks * gridDim.z + b) * N + qi) * C + head * D + kq * 4;
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt) *reinterpret_cast<f32x4*>(orow + tt * 16) = o[qm][tt];
+            if (kq == 0) {
+                float* ml = part_ml + ((((size_t)ks * gridDim.z + b) * heads + head) * N + qi) * 2;
+                ml[0] = m[qm]; ml[1] = l[qm];
+            }
+        }
     }
 }
 
+// out[b][q][head*D + d] = sum_s O_s 2^(m_s - M) / (sum_s l_s 2^(m_s - M)) / (2^4 * 2^10), M = max_s m_s; splits in order.
+__global__ __launch_bounds__(256)
+void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out,
+                              int B, int N, int C, int D, int heads, int ksplit) {
+    const int CQ = C >> 2;
+    const size_t total = (size_t)B * N * CQ;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cq = (int)(idx % CQ);
+    const size_t bq = idx / CQ;                       // b * N + q
+    const int q = (int)(bq % N), b = (int)(bq / N);
+    const int head = (cq * 4) / D;
+    float mv[A16_MAX_SPLIT], lv[A16_MAX_SPLIT];
+    float M = -INFINITY;
+    for (int s = 0; s < ksplit; ++s) {
+        const float* ml = part_ml + ((((size_t)s * B + b) * heads + head) * N + q) * 2;
+        mv[s] = ml[0]; lv[s] = ml[1];
+        M = fmaxf(M, mv[s]);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float w = __builtin_amdgcn_exp2f(mv[s] - M);
+        L += lv[s] * w;
+        acc += *reinterpret_cast<const f32x4*>(part_o + (((size_t)s * B + b) * N + q) * C + cq * 4) * w;
+    }
+    *reinterpret_cast<f32x4*>(out + bq * C + cq * 4) = acc * (1.0f / (L * A16_QKV_SCALE * A16_P_SCALE));
+}
+
+static int att16_npad(int N) { return ((N + 63) / 64) * 64; }
+
 size_t attention16_scratch_bytes(int B, int N, int C) {
-    const size_t npad = (size_t)((N + 63) / 64) * 64;
-    return (size_t)B * 2 * ((size_t)N * C + (size_t)C * npad) * sizeof(_Float16) + 512;   // Kp + Vp (C = heads*D)
+    const size_t npad = (size_t)att16_npad(N);
+    const size_t kv = 2 * ((size_t)B * 2 * npad * C * sizeof(_Float16) + 256);                       // Kp + Vp (C = heads*D)
+    const size_t part = (size_t)A16_MAX_SPLIT * B * ((size_t)N * C + 2 * (size_t)N * 2) * sizeof(float) + 512;   // split partials (2 heads)
+    return kv + part;
 }
 
 hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int N, int C, int heads, hipStream_t s) {
     const int D = C / heads;
-    if (C % heads || !attention_supported(D) || D % 32) return hipErrorInvalidValue;
+    if (C % heads || !attention_supported(D) || D % 32 || heads != 2) return hipErrorInvalidValue;
     const float qscale = (float)((1.0 / sqrt((double)D)) * 1.4426950408889634);
-    const int Npad = ((N + 63) / 64) * 64;
-    _Float16* Kp = reinterpret_cast<_Float16*>(scratch);
-    _Float16* Vp = Kp + (((size_t)B * 2 * N * C + 127) / 128) * 128;
-    hipLaunchKernelGGL(attention_prep_kernel, dim3(Npad / 64, heads, B), dim3(256), 0, s, qkv, Kp, Vp, N, Npad, C, D, heads);
+    const int Npad = att16_npad(N);
+    char* sp = reinterpret_cast<char*>(scratch);
+    const size_t kbytes = (((size_t)B * 2 * Npad * C * sizeof(_Float16)) + 255) & ~(size_t)255;
+    _Float16* Kp = reinterpret_cast<_Float16*>(sp);
+    _Float16* Vp = reinterpret_cast<_Float16*>(sp + kbytes);
+    float* part_o = reinterpret_cast<float*>(sp + 2 * kbytes);
+    float* part_ml = part_o + (size_t)A16_MAX_SPLIT * B * N * C;
+    hipLaunchKernelGGL(attention_prep_kernel, dim3(Npad / 32, heads, B), dim3(256), 0, s, qkv, Kp, Vp, N, Npad, C, D, heads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 64 queries per workgroup, or 32 when that leaves CUs idle (split half-batches at B = 8: 128 workgroups)
-    static const int small_ok = getenv("MIDD_ATT_SMALL") ? atoi(getenv("MIDD_ATT_SMALL")) : 0;   // measured: 64-query workgroups win even at 128 workgroups
-    const bool small = small_ok && (long)((N + 63) / 64) * heads * B < 256;
-#define MIDD_ATT(DD)                                                                                              \
-    if (small) hipLaunchKernelGGL((attention_f16x3_kernel<DD, 2>), dim3((N + 31) / 32, heads, B), dim3(128), 0, s, \
-                                  qkv, Kp, Vp, out, N, Npad, C, qscale);                                          \
-    else hipLaunchKernelGGL((attention_f16x3_kernel<DD, 4>), dim3((N + 63) / 64, heads, B), dim3(256), 0, s,      \
-                            qkv, Kp, Vp, out, N, Npad, C, qscale);
+    // split the keys until ~512 workgroups exist (two per CU), keeping at least two 32-key tiles per split
+    const int qblocks = (N + A16_QB - 1) / A16_QB, tiles = (N + A16_KT - 1) / A16_KT;
+    static const int want_wgs = getenv("MIDD_ATT_WGS") ? atoi(getenv("MIDD_ATT_WGS")) : 384;
+    int ksplit = 1;
+    while ((long)qblocks * heads * B * ksplit < want_wgs && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
+    const int tps = (tiles + ksplit - 1) / ksplit;
+    if ((long)(ksplit - 1) * tps >= tiles) return hipErrorInvalidValue;        // every split owns at least one tile that starts below N
+#define MIDD_ATT(DD)                                                                                                        \
+    {                                                                                                                       \
+        constexpr int lds_bytes = 2 * Att16Geom<DD>::STAGE;                                                                 \
+        static bool raised = false;                                                                                         \
+        if (lds_bytes > 64 * 1024 && !raised) {                                                                             \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x3_kernel<DD>),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                 \
+            if (e != hipSuccess) return e;                                                                                  \
+            raised = true;                                                                                                  \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((attention_f16x3_kernel<DD>), dim3(qblocks * ksplit, heads, B), dim3(256), lds_bytes, s,         \
+                           qkv, Kp, Vp, out, part_o, part_ml, N, Npad, C, qscale, ksplit, tps);                             \
+    }
     switch (D) {
         case 32:  MIDD_ATT(32) break;
         case 64:  MIDD_ATT(64) break;
@@ -299,6 +390,11 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
         case 128: MIDD_ATT(128) break;
     }
 #undef MIDD_ATT
+    e = hipGetLastError();
+    if (e != hipSuccess || ksplit == 1) return e;
+    const size_t total = (size_t)B * N * (C / 4);
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       part_o, part_ml, out, B, N, C, D, heads, ksplit);
     return hipGetLastError();
 }
 

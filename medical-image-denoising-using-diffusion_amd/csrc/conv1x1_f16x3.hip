@@ -14,7 +14,6 @@
 // Epilogue and contract are those of conv_mfma_f16x3.hip (bias / time embedding / residual, GroupNorm partial
 // sums of the output per (workgroup, wave) row).  Weight pack: pack_conv_f16x3 (midd_api.hip), 32 channels per step.
 #include "f16x3_common.h"
-#include "stats_common.h"
 #include <cstdlib>
 
 namespace midd {
@@ -26,12 +25,7 @@ struct Conv1Geom {
     static constexpr int WSTEP = NT * 2048;                  // bytes of one K-step's weights (hi + lo, NT cout tiles)
     static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
     static constexpr int ADD_FLOATS = NT * 16;
-    // the weight image doubles as the scratch of the statistics fold at the end
-    __host__ __device__ static int weight_bytes(int cin) {
-        const int w = ((cin + 31) / 32) * WSTEP, f = stats_scratch_doubles(NTHREADS) * 8;
-        return w < f ? f : w;
-    }
-    static int lds_bytes(int cin) { return weight_bytes(cin) + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
+    static int lds_bytes(int cin) { return ((cin + 31) / 32) * WSTEP + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
 };
 
 template <int MT, int NT>
@@ -58,7 +52,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     const int ntile_wg = blockIdx.y * NT;
 
     char* const wl = lds;                                                        // [step][NT][hi|lo][lane] x 16 B
-    float* const stat_lds = reinterpret_cast<float*>(wl + G::weight_bytes(Cin));  // [wave][2][NT*16]
+    float* const stat_lds = reinterpret_cast<float*>(wl + nsteps * WSTEP);       // [wave][2][NT*16]
     float* const add_lds = stat_lds + G::STAT_FLOATS;                            // [NT*16]
     float* const gnp = add_lds + G::ADD_FLOATS;                                  // [2][Cin] scale, shift
 
@@ -137,7 +131,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (a.stat_partial != nullptr) {
+        if (a.stat_tot != nullptr) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -213,8 +207,8 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         if (s + 1 < total) compute(ra[1], s + 3 < total);
     }
 
-    // ---- publish the GroupNorm partial sums: one row per workgroup (the waves' rows folded in a fixed order) ----
-    if (a.stat_partial != nullptr) {
+    // ---- the workgroup's per-channel sums (waves' rows folded in a fixed order) -> the tensor's totals ----
+    if (a.stat_tot != nullptr) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -224,12 +218,8 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
-            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + first_tile) * 2 + which) * a.Cout + ntile_wg * 16 + c], t);
+            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + ntile_wg * 16 + c) * 2 + which) * STAT_LIMBS, t);
         }
-        // the weight image is idle now: fold scratch (lds_bytes() reserves at least that much)
-        stats_arrive_and_fold<G::NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, ntile_wg * 16,
-                                           NT * 16, a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
-                                           a.wgs_per_img, reinterpret_cast<double*>(wl));
     }
 }
 

@@ -15,7 +15,6 @@
 // c+1, which waits for all but the (D-1) youngest weight groups, has it landed; in steps 1..D of chunk c it is
 // younger than the group waited for and is added to the count.
 #include "f16x3_common.h"
-#include "stats_common.h"
 #include <cstdlib>
 
 namespace midd {
@@ -207,7 +206,7 @@ void conv3x3_pre_f16x3_kernel(const ConvArgs a) {
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (a.stat_partial != nullptr) {
+        if (a.stat_tot != nullptr) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -268,22 +267,17 @@ void conv3x3_pre_f16x3_kernel(const ConvArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight refills issued past the last step
 
-    // ---- one GroupNorm partial row per workgroup ------------------------------------------------------
-    if (a.stat_partial != nullptr) {
+    // ---- the workgroup's per-channel sums -> the tensor's totals (stats_common.h) -----------------------------
+    if (a.stat_tot != nullptr) {
         lds_barrier();
-        const int row = blockIdx.x - b * a.wgs_per_img;
         constexpr int ROWF = 2 * NT * 16;
         for (int i = tid; i < ROWF; i += NTHREADS) {
             const int which = i / (NT * 16), c = i - which * (NT * 16);
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < NW; ++m) t += stat_lds[m * ROWF + i];
-            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + ntile_wg * 16 + c], t);
+            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + ntile_wg * 16 + c) * 2 + which) * STAT_LIMBS, t);
         }
-        static_assert(2 * G::IMG_BYTES >= stats_scratch_doubles(NTHREADS) * 8, "fold scratch");
-        stats_arrive_and_fold<NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, ntile_wg * 16,
-                                        NT * 16, a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
-                                        a.wgs_per_img, reinterpret_cast<double*>(img0));
     }
 }
 

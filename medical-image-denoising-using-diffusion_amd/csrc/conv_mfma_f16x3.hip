@@ -27,7 +27,6 @@
 // K walk: 32 input channels (two 16-channel blocks) per step and tap; a trailing single block
 // (Cin = 48, 144) pairs two TAPS per step instead.
 #include "f16x3_common.h"
-#include "stats_common.h"
 #include <cstdlib>
 #include <type_traits>
 #ifdef MIDD_CONV_TIMING
@@ -399,7 +398,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
-        if (a.stat_partial != nullptr) {
+        if (a.stat_tot != nullptr) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -413,14 +412,13 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             }
         }
     };
-    // one row per workgroup: the waves' LDS rows are folded over wm in a fixed order after a barrier and stored
-    // write-through; the last workgroup of this (sample, cout slice) folds the slice's rows into the channel totals
+    // the waves' LDS rows are folded over wm in a fixed order after a barrier; the workgroup's per-channel sums go to
+    // the tensor's totals with exact integer atomics (stats_common.h)
     auto publish_stats = [&]() {
-        if (a.stat_partial == nullptr) return;
+        if (a.stat_tot == nullptr) return;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int row = blockIdx.x - b * a.wgs_per_img;
         constexpr int ROWF = 2 * NT * 16;                              // floats of one wave's row
         for (int i = tid; i < WN * ROWF; i += NTHREADS) {
             const int wn_i = i / ROWF, r = i - wn_i * ROWF;
@@ -428,12 +426,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
-            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + row) * 2 + which) * a.Cout + (ntile_wg + wn_i * NT) * 16 + c], t);
+            const int ch = (ntile_wg + wn_i * NT) * 16 + c;
+            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + ch) * 2 + which) * STAT_LIMBS, t);
         }
-        static_assert(G::RAW_BYTES + G::IMG_BYTES + RING * WSLICE >= stats_scratch_doubles(NTHREADS) * 8, "fold scratch (raw buffer, image and weight ring: all idle here)");
-        stats_arrive_and_fold<NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, ntile_wg * 16,
-                                        WN * NT * 16, a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
-                                        a.wgs_per_img, reinterpret_cast<double*>(raw));
     };
 
     // ---- tile / chunk loop -----------------------------------------------------------------------
@@ -589,17 +584,6 @@ int conv16_wgs_per_img(int tiles, int B, int ny, int target) {
     if (per_img > tiles) per_img = tiles;
     const int tiles_per_wg = (tiles + per_img - 1) / per_img;
     return (tiles + tiles_per_wg - 1) / tiles_per_wg;
-}
-
-int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout, int persist_wgs) {
-    if (compute_mode == MODE_F16X3 && t.tw == 0) {           // flattened-pixel 1x1 kernel
-        const int bm1 = t.wm * t.mt * 16;
-        return conv16_wgs_per_img((OH * OW + bm1 - 1) / bm1, B, Cout / (t.wn * t.nt * 16), persist_wgs);
-    }
-    const int bm = t.wm * t.mt * 16, th = bm / t.tw;
-    const int tiles = ((OW + t.tw - 1) / t.tw) * ((OH + th - 1) / th);
-    if (compute_mode == MODE_F16X3) return conv16_wgs_per_img(tiles, B, Cout / (t.wn * t.nt * 16), persist_wgs);   // one row per workgroup
-    return tiles;                                            // fp32 kernel: one row per tile
 }
 
 #define MIDD_CONV16_TILES(X)                  \

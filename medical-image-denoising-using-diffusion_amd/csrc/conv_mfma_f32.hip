@@ -23,7 +23,6 @@
 // global loads are in flight while the current chunk's 9*4*MT*NT MFMAs run.  Weights are
 // L2-resident (<= 2.6 MB per layer) and go straight to registers, one tap ahead.
 #include "midd_internal.h"
-#include "stats_common.h"
 
 namespace midd {
 
@@ -50,7 +49,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     static_assert(NTHREADS % 4 == 0, "quad id must be thread-constant");
 
     __shared__ f32x4 lds[2][NSLOT];
-    __shared__ double fold_scratch[NTHREADS * 4];          // statistics: wave rows, then the last arriver's fold
+    __shared__ float fold_scratch[WM * WN * 2 * NT * 16];  // statistics: one row per wave
     extern __shared__ float gnp[];                         // [2][Cin] GroupNorm scale, shift of this sample
 
     const int tid = threadIdx.x;
@@ -217,11 +216,11 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             }
         }
     }
-    if (a.stat_partial != nullptr) {
+    if (a.stat_tot != nullptr) {
         // per-channel partial sums of the output for the next GroupNorm: the 16 pixel lanes are folded with
-        // fixed-order shuffles, the WM wave rows through LDS, ONE row per tile is stored write-through and the last
-        // tile of this (sample, cout slice) folds the slice's rows into the channel totals (stats_common.h)
-        float* const wrow = reinterpret_cast<float*>(fold_scratch);          // [wave][2][NT*16]
+        // fixed-order shuffles, the WM wave rows through LDS, and the tile's sums go to the tensor's totals with exact
+        // integer atomics (stats_common.h)
+        float* const wrow = fold_scratch;                                    // [wave][2][NT*16]
         constexpr int ROWF = 2 * NT * 16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -245,11 +244,8 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + r];
-            stat_store(&a.stat_partial[((size_t)(b * a.stat_rows + trem) * 2 + which) * a.Cout + c0 + wn_i * NT * 16 + c], t);
+            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + c0 + wn_i * NT * 16 + c) * 2 + which) * STAT_LIMBS, t);
         }
-        stats_arrive_and_fold<NTHREADS>(a.stat_partial + (size_t)b * a.stat_rows * 2 * a.Cout, a.stat_rows, a.Cout, c0, WN * NT * 16,
-                                        a.stat_tot + (size_t)b * a.Cout * 2, a.stat_cnt + b * gridDim.y + blockIdx.y,
-                                        tiles_per_img, fold_scratch);
     }
 }
 

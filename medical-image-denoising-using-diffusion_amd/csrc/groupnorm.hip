@@ -2,13 +2,12 @@
 //
 // nn.GroupNorm(8, C) on the reference's hot path (/root/reference/Backend/DDIM/DDIMModel.py:116,121,139,214; eps =
 // 1e-5, affine) never runs as a kernel of its own here (stats_common.h): the PRODUCER of a tensor leaves per-channel
-// fp64 (sum, sum of squares) totals, the CONSUMER derives scale = rstd * gamma, shift = beta - mean * rstd * gamma in
+// fixed-point (sum, sum of squares) totals, the CONSUMER derives scale = rstd * gamma, shift = beta - mean * rstd * gamma in
 // its prologue and applies x * scale + shift (+SiLU) while staging its input.  This file holds
 //   chan_total_kernel  the totals of tensors no MFMA convolution produced (in_conv output, bilinear 2x outputs,
 //                      unfolded ConvTranspose outputs): one read of the tensor, HBM-bound;
 //   preact_kernel      opt-in pre-activation pass for conv3x3_pre_f16x3.hip (PRO_PRE_DMA).
 #include "midd_internal.h"
-#include "stats_common.h"
 
 namespace midd {
 
@@ -17,12 +16,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int GN_THREADS = 256;
 
 // grid (rows, B): block `row` sums a contiguous pixel range of sample b per channel in fp64 (products of fp32 values
-// are exact in fp64), stores its row [2][C] (fp32, write-through); the block that arrives last at cnt[b] folds the
-// rows of the sample in a fixed order into tot [B][C][2].
+// are exact in fp64), rounds the block's sums to fp32 and adds them to tot [B][C][2][3] with exact integer atomics.
 __global__ __launch_bounds__(GN_THREADS)
-void chan_total_kernel(const float* __restrict__ src, float* __restrict__ part, double* __restrict__ tot, int* __restrict__ cnt,
-                       int HW, int C, int rows) {
-    extern __shared__ double red[];               // max([ppi][C][2], fold scratch)
+void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int HW, int C, int rows) {
+    extern __shared__ double red[];               // [ppi][C][2]
     const int CQ = C >> 2;
     const int ppi = GN_THREADS / CQ;
     const int tid = threadIdx.x;
@@ -48,10 +45,9 @@ void chan_total_kernel(const float* __restrict__ src, float* __restrict__ part, 
     for (int c = tid; c < C; c += GN_THREADS) {
         double cs = 0, css = 0;
         for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
-        float* o = part + ((size_t)(b * rows + row) * 2) * C + c;
-        stat_store(o, (float)cs); stat_store(o + C, (float)css);
+        stat_word* o = tot + ((size_t)b * C + c) * STAT_WORDS;
+        stat_atomic_add(o, (float)cs); stat_atomic_add(o + STAT_LIMBS, (float)css);
     }
-    stats_arrive_and_fold<GN_THREADS>(part + (size_t)b * rows * 2 * C, rows, C, 0, C, tot + (size_t)b * C * 2, cnt + b, rows, red);
 }
 
 int chan_partial_rows(int HW, int C) {
@@ -62,12 +58,11 @@ int chan_partial_rows(int HW, int C) {
     return r;
 }
 
-hipError_t chan_total_launch(const float* src, float* part, double* tot, int* cnt, int B, int HW, int C, int rows, hipStream_t s) {
-    if (C % 4 || C / 4 > GN_THREADS / 2) return hipErrorInvalidValue;        // the fold needs 2*C/4 column quads <= 256 threads
+hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, int C, int rows, hipStream_t s) {
+    if (C % 4 || C / 4 > GN_THREADS) return hipErrorInvalidValue;
     const int ppi = GN_THREADS / (C / 4);
-    size_t lds = (size_t)ppi * C * 2 * sizeof(double);
-    if (lds < (size_t)stats_scratch_doubles(GN_THREADS) * sizeof(double)) lds = (size_t)stats_scratch_doubles(GN_THREADS) * sizeof(double);
-    hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, part, tot, cnt, HW, C, rows);
+    const size_t lds = (size_t)ppi * C * 2 * sizeof(double);
+    hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, tot, HW, C, rows);
     return hipGetLastError();
 }
 

@@ -58,8 +58,8 @@ struct HostWeight { std::vector<int64_t> shape; std::vector<float> data; bool lo
 
 struct TensorRef {
     size_t off = 0; int C = 0, H = 0, W = 0;
-    // GroupNorm statistics, if produced: partial rows [B][rows][2][C] fp32 and per-channel totals [B][C][2] fp64
-    size_t stat_off = (size_t)-1, tot_off = (size_t)-1; int stat_rows = 0;
+    // GroupNorm statistics, if produced: per-channel fixed-point totals [B][C][2][3] (stats_common.h), inside the statistics arena
+    size_t tot_off = (size_t)-1;
 };
 
 struct GnRef { size_t gamma = 0, beta = 0; bool on = false; };        // affine of the GroupNorm in front of a consumer
@@ -72,7 +72,7 @@ struct Op {
     bool has_s1 = false, has_resid = false;
     GnRef gn;                   // OP_CONV / OP_PREACT / OP_OUT: GroupNorm of (s0, s1) applied while staging
     size_t partial_off = 0;     // OP_ATTN: pre-split K / V^T scratch
-    int cnt_index = -1;         // producers of statistics: first arrival counter (B * slices of them)
+    int stat_rows = 0;          // OP_CHAN_TOT: blocks per sample
     // OP_CONV
     size_t w = 0, b = 0;
     int prologue = PRO_RAW, temb_col = -1;
@@ -87,7 +87,7 @@ struct Program {
     int persist_wgs = 0;       // f16x3 convs: persistent-workgroup target of this program (0 = default)
     std::vector<Op> ops;
     size_t bytes = 0, trow_off = 0, sched_off = 0, counter_off = 0;
-    size_t cnt_off = 0; int cnt_slots = 0;      // arrival counters of the statistics hand-off (zeroed once per library call)
+    size_t stats_off = 0, stats_bytes = 0;      // statistics arena: every tensor's totals, zeroed by one memset per forward
     std::map<std::string, TensorRef> outputs;
 };
 
@@ -579,17 +579,17 @@ struct Builder {
         t.off = bump.take((size_t)B * H * W * C * sizeof(float));
         return t;
     }
-    int take_counters(int n) { const int i = g->cnt_slots; g->cnt_slots += n; return i; }
-    void alloc_stats(TensorRef& t, int rows) {
-        t.stat_rows = rows;
-        t.stat_off = bump.take((size_t)B * rows * 2 * t.C * sizeof(float));
-        t.tot_off = bump.take((size_t)B * t.C * 2 * sizeof(double));
+    // totals live in one arena (offsets relative to it until build_program places it) so ONE memset clears them all
+    size_t stats_cur = 0;
+    void alloc_stats(TensorRef& t) {
+        t.tot_off = stats_cur;
+        stats_cur += ((size_t)B * t.C * STAT_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
     }
     // per-channel totals for a tensor no MFMA convolution produced
     void ensure_stats(TensorRef& t) {
         if (t.tot_off != (size_t)-1) return;
-        alloc_stats(t, chan_partial_rows(t.H * t.W, t.C));
-        Op o{}; o.kind = OP_CHAN_TOT; o.s0 = t; o.cnt_index = take_counters(B); g->ops.push_back(o);
+        alloc_stats(t);
+        Op o{}; o.kind = OP_CHAN_TOT; o.s0 = t; o.stat_rows = chan_partial_rows(t.H * t.W, t.C); g->ops.push_back(o);
     }
     int conv(const TensorRef& s0, const TensorRef* s1, TensorRef& dst, size_t w, size_t b, float wscale, int ks, int stride,
              int prologue, GnRef gn, int temb_col, const TensorRef* resid, bool want_stats) {
@@ -617,11 +617,7 @@ struct Builder {
             g->ops.push_back(pre);
             o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE_DMA; o.gn = GnRef{};
         }
-        if (want_stats) {
-            alloc_stats(dst, conv_stat_rows(p->cfg.compute_mode, o.tile, B, dst.H, dst.W, dst.C, g->persist_wgs));
-            o.cnt_index = take_counters(B * (dst.C / (o.tile.wn * o.tile.nt * 16)));
-            o.want_stats = true;
-        }
+        if (want_stats) { alloc_stats(dst); o.want_stats = true; }
         o.dst = dst;
         g->ops.push_back(o);
         return MI_OK;
@@ -735,7 +731,13 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     if (h.H != H || h.W != W) return fail(MI_EINVAL, "network output is %dx%d for a %dx%d input", h.H, h.W, H, W);
     if (h.tot_off == (size_t)-1) return fail(MI_EINVAL, "internal: network output without statistics");
     { Op o{}; o.kind = OP_OUT; o.s0 = h; o.gn = GnRef{p->g_out, p->be_out, true}; g->ops.push_back(o); }
-    g->cnt_off = bld.bump.take((size_t)(g->cnt_slots + 4) * sizeof(int));
+    // place the statistics arena and make the tensors' offsets absolute
+    g->stats_bytes = bld.stats_cur;
+    g->stats_off = bld.bump.take(g->stats_bytes);
+    for (Op& o : g->ops)
+        for (TensorRef* t : {&o.s0, &o.s1, &o.dst, &o.resid})
+            if (t->tot_off != (size_t)-1) t->tot_off += g->stats_off;
+    for (auto& kv : g->outputs) if (kv.second.tot_off != (size_t)-1) kv.second.tot_off += g->stats_off;
     g->bytes = (bld.bump.cur + 255) & ~(size_t)255;
     return MI_OK;
 }
@@ -843,8 +845,9 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
-    auto D = [&](size_t off) { return reinterpret_cast<double*>(ws + off); };
-    int* const cnt = reinterpret_cast<int*>(ws + g->cnt_off);
+    auto T = [&](size_t off) { return reinterpret_cast<stat_word*>(ws + off); };
+    // every tensor's GroupNorm totals start the forward at zero (producers accumulate with atomics)
+    if (hipMemsetAsync(ws + g->stats_off, 0, g->stats_bytes, s) != hipSuccess) return fail(MI_EHIP, "clearing the statistics arena failed");
     for (const Op& o : g->ops) {
         hipError_t e = hipSuccess;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -867,7 +870,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             case OP_PREACT: {
                 PreactArgs a{};
                 a.src0 = F(o.s0.off); a.C0 = o.s0.C; a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
-                a.gn_tot0 = D(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? D(o.s1.tot_off) : nullptr;
+                a.gn_tot0 = T(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : nullptr;
                 a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                 a.silu = o.prologue == PRO_GN_SILU ? 1 : 0; a.out = reinterpret_cast<unsigned*>(ws + o.dst.off);
                 a.B = B; a.HW = o.s0.H * o.s0.W;
@@ -875,8 +878,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 break;
             }
             case OP_CHAN_TOT:
-                e = chan_total_launch(F(o.s0.off), F(o.s0.stat_off), D(o.s0.tot_off), cnt + o.cnt_index, B, o.s0.H * o.s0.W,
-                                      o.s0.C, o.s0.stat_rows, s);
+                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
                 break;
             case OP_CONV: {
                 ConvArgs a{};
@@ -886,13 +888,13 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue;
                 if (o.gn.on) {
-                    a.gn_tot0 = D(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? D(o.s1.tot_off) : nullptr;
+                    a.gn_tot0 = T(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : nullptr;
                     a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f; a.gn_hw = o.s0.H * o.s0.W;
                 }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
                 a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;
-                if (o.want_stats) { a.stat_partial = F(o.dst.stat_off); a.stat_rows = o.dst.stat_rows; a.stat_tot = D(o.dst.tot_off); a.stat_cnt = cnt + o.cnt_index; }
+                if (o.want_stats) a.stat_tot = T(o.dst.tot_off);
                 a.persist_wgs = g->persist_wgs;
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
                 break;
@@ -910,7 +912,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 break;
             case OP_OUT: {
                 OutConvArgs a{};
-                a.src = F(o.s0.off); a.gn_tot = D(o.s0.tot_off); a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
+                a.src = F(o.s0.off); a.gn_tot = T(o.s0.tot_off); a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                 a.w = wd + p->w_out; a.bias = wd + p->b_out;
                 a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
                 a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;
@@ -945,12 +947,6 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
     return MI_OK;
 }
 
-// The arrival counters of the statistics hand-off (stats_common.h) start every library call at zero; inside a call the
-// last arriver of each launch resets its counter, so one memset per call (not per launch) is enough.
-static hipError_t reset_counters(const Program* g, char* ws, hipStream_t s) {
-    return hipMemsetAsync(ws + g->cnt_off, 0, (size_t)(g->cnt_slots + 4) * sizeof(int), s);
-}
-
 static int check_call(mi_plan* plan, int B, int H, int W, void* ws, size_t ws_bytes, Program** g) {
     if (!plan) return fail(MI_EINVAL, "null plan");
     int rc = get_program(plan, B, H, W, g);
@@ -975,7 +971,6 @@ extern "C" int mi_unet_forward(mi_plan* plan, const float* x, const float* condi
     char* ws = (char*)workspace;
     hipError_t e = fill_i32_launch(reinterpret_cast<int*>(ws + g->trow_off), t, B, s);
     if (e != hipSuccess) return fail(MI_EHIP, "fill timesteps: %s", hipGetErrorString(e));
-    HIPCHK(reset_counters(g, ws, s));
     StepIO io{x, condition, eps, nullptr, nullptr, 0.f, 0.f, 0.f, 0};
     return run_program(plan, g, io, ws, s);
 }
@@ -1031,7 +1026,6 @@ static int denoise_graph(mi_plan* plan, Program* g, const float* noisy, float* x
     HIPCHK(hipStreamWaitEvent(gs, plan->gev_in, 0));
     HIPCHK(hipMemcpyAsync(ws + g->sched_off, sched.data(), sched.size() * sizeof(StepSched), hipMemcpyHostToDevice, gs));
     HIPCHK(hipMemsetAsync(ws + g->counter_off, 0, sizeof(int), gs));
-    HIPCHK(reset_counters(g, ws, gs));
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, gs));   // x = noisy_img.clone()
     for (int i = 0; i < n_iters; ++i) HIPCHK(hipGraphLaunch(exec, gs));
     HIPCHK(hipEventRecord(plan->gev_out, gs));
@@ -1094,7 +1088,6 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         // From here on the side streams may hold work on x_out and the workspace: whatever happens in the loop,
         // the caller's stream waits for them before this call returns (the caller frees / reuses both).
         auto enqueue_all = [&]() -> int {
-            for (int h = 0; h < parts; ++h) HIPCHK(reset_counters(gh, ws + (size_t)h * gh->bytes, h ? plan->sstream[h] : s));
             for (int i = 0; i < n_iters; ++i) {
                 const int t = t_list[i];
                 for (int h = 0; h < parts; ++h) {
@@ -1125,7 +1118,6 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         }
         return rc;
     }
-    HIPCHK(reset_counters(g, ws, s));
     for (int i = 0; i < n_iters; ++i) {
         const int t = t_list[i];
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(ws + g->trow_off), t, B, s));                     // t = full((B,), i)

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "stats_common.h"
 
 namespace midd {
 
@@ -22,10 +23,10 @@ struct ConvArgs {
     const float* wpack;     // [Cin/16][taps][Cout/16][64 lanes][4]  (MFMA A-fragment order)
     const float* bias;      // [Cout]
     int Cout;
-    // GroupNorm of the INPUT (prologue != RAW): per-channel fp64 (sum, sum of squares) totals of the two concatenated
-    // sources, [B][C0][2] / [B][C1][2], written by the producers' last-arriving workgroups (stats_common.h); every
+    // GroupNorm of the INPUT (prologue != RAW): per-channel fixed-point (sum, sum of squares) totals of the two
+    // concatenated sources, [B][C0][2][3] / [B][C1][2][3] limbs, accumulated by the producers (stats_common.h); every
     // workgroup derives scale = rstd*gamma, shift = beta - mean*rstd*gamma of its sample in its prologue
-    const double* gn_tot0; const double* gn_tot1;
+    const stat_word* gn_tot0; const stat_word* gn_tot1;
     const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_hw;      // affine [Cin], eps, pixels per channel
     int prologue;
     const float* temb;      // time table [rows][temb_stride], already offset to this block's column
@@ -35,16 +36,12 @@ struct ConvArgs {
     float* out;             // NHWC [B][OH][OW][Cout]
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     const float* zeros;     // (unused) 64 zero floats
-    // optional fused GroupNorm statistics of the OUTPUT: per (sample, row, channel) partial sum and sum of squares,
-    // layout [B][stat_rows][2][Cout], one row per workgroup (f16x3: persistent workgroup; f32: tile); the last
-    // workgroup to arrive at stat_cnt[b * gridDim.y + blockIdx.y] folds its cout slice into stat_tot [B][Cout][2]
-    float* stat_partial;
-    int stat_rows;
-    double* stat_tot;
-    int* stat_cnt;
+    // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
+    // the pixels it produced to the totals [B][Cout][2][3] (exact integer atomics, stats_common.h); zeroed per forward
+    stat_word* stat_tot;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
-    int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default), must match conv_stat_rows
+    int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default)
 #ifdef MIDD_CONV_TIMING
     int dbg_slot;           // diagnostic build: row of g_conv_timing
 #endif
@@ -59,8 +56,6 @@ enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
 // Picks a tile for (Cout, output pixels, kernel size, stride); returns false if unsupported.
 bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
 hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
-// rows of the fused-statistics buffer one launch with this tile writes per image
-int conv_stat_rows(int compute_mode, const ConvTile& t, int B, int OH, int OW, int Cout, int persist_wgs = 0);
 
 // split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
 bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
@@ -85,15 +80,15 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
 // ---------------------------------------------------------------- GroupNorm statistics (stats_common.h)
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
 // per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
-// sample write partial rows [B][rows][2][C]; the last one to arrive at cnt[b] folds them into tot [B][C][2]
-hipError_t chan_total_launch(const float* src, float* part, double* tot, int* cnt, int B, int HW, int C, int rows, hipStream_t s);
+// sample each add their partial sums to tot [B][C][2][3]
+hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
 // GroupNorm-apply (+SiLU) + 2^s prescale + fp16 hi/lo split of a (virtually concatenated) NHWC tensor into the planar
 // operand image of PRO_PRE_DMA convolutions (groupnorm.hip)
 struct PreactArgs {
     const float* src0; const float* src1; int C0, C1;
-    const double* gn_tot0; const double* gn_tot1; const float* gn_gamma; const float* gn_beta; float gn_eps;
+    const stat_word* gn_tot0; const stat_word* gn_tot1; const float* gn_gamma; const float* gn_beta; float gn_eps;
     int silu; unsigned* out; int B, HW;
 };
 hipError_t preact_launch(const PreactArgs& a, hipStream_t s);
@@ -123,7 +118,7 @@ hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9
 
 struct OutConvArgs {
     const float* src;       // NHWC [B][H][W][C]
-    const double* gn_tot; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][2], affine [C]
+    const stat_word* gn_tot; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][2][3], affine [C]
     const float* w;         // [ic][9][C]
     const float* bias;      // [ic]
     int B, H, W, C, ic;

@@ -10,7 +10,6 @@
 // K = 18 and N = 1 are degenerate GEMM shapes: these stay on the vector ALU and are judged
 // against the HBM roofline.
 #include "midd_internal.h"
-#include "stats_common.h"
 
 namespace midd {
 

@@ -1,102 +1,58 @@
-// GroupNorm statistics without a kernel of their own (replaces gn_from_partial_kernel: 51 launches per forward).
+// GroupNorm statistics without a kernel, a reduction pass or a hand-off of their own (replaces gn_from_partial_kernel:
+// 51 launches per forward).
 //
 // nn.GroupNorm(8, C) (/root/reference/Backend/DDIM/DDIMModel.py:116,121,139,214) needs, per sample and group, the
 // mean and variance of a tensor that a previous kernel produced.  Here
-//   PRODUCER  every workgroup writes ONE row of per-channel partial sums (sum, sum of squares; fp32) of the pixels it
-//             produced, [B][rows][2][C]; the workgroup of a (sample, cout slice) that arrives LAST folds that slice's
-//             rows in a fixed order in fp64 into per-channel totals [B][C][2] (stats_arrive_and_fold);
+//   PRODUCER  every workgroup adds its per-channel partial sums (sum, sum of squares; fp32, folded over its waves
+//             in a fixed order) to per-channel TOTALS with integer atomics.  A total is a 120-bit fixed-point
+//             number in three int64 limbs of 40 value bits each (resolution 2^-60, range +-2^59; 24 spare bits per
+//             limb absorb up to 2^23 additions without a carry): the fp32 partial converts EXACTLY, integer addition
+//             is associative, so the totals are exact and independent of the order in which workgroups finish --
+//             bit-deterministic without a fixed-order reduction pass;
 //   CONSUMER  derives scale = rstd * gamma, shift = beta - mean * rstd * gamma of ITS sample in its prologue from the
-//             per-channel totals of up to two (torch.cat) sources (gn_prologue_lds): one 16-byte load per channel,
-//             a fixed-order wave reduction per group, so every workgroup of every launch gets identical bits.
-// Hand-off inside the producer launch (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md
-// Guideline 16, recipe R1 in its counter form): rows are stored write-through (agent-scope relaxed atomic store =
-// global_store ... sc1), every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane does the
-// agent-scope fetch-add on the slice's arrival counter; the workgroup whose add returns expected-1 is last: one lane
-// runs the agent-scope acquire (buffer_inv sc1), waits for it, workgroup barrier, then plain loads.  The totals are
-// read by LATER kernels only (kernel boundary).  The last arriver resets the counter, so one memset of the counter
-// block per library call (not per launch) keeps them initialised.
+//             totals of up to two (torch.cat) sources (gn_prologue_lds): limbs -> fp64, a fixed-order wave
+//             reduction per group, so every workgroup of every launch gets identical bits.
+// Producer and consumers are different kernels (kernel boundary = visibility); one memset of the whole statistics
+// arena per forward pass zeroes the totals.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace midd {
 
 constexpr int GN_GROUPS_C = 8;                    // nn.GroupNorm(8, C) everywhere in the reference
+constexpr int STAT_LIMBS = 3;                     // int64 limbs per total
+constexpr int STAT_WORDS = 2 * STAT_LIMBS;        // per channel: sum, sum of squares
+typedef unsigned long long stat_word;
 
-__device__ __forceinline__ void stat_store(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // write-through (sc1)
+// totals[k] += limb k of v * 2^60 (exact for 2^-37 <= |v| < 2^59; smaller magnitudes are truncated towards zero at
+// 2^-60, far below fp32 resolution of any sum they could matter in)
+__device__ __forceinline__ void stat_atomic_add(stat_word* limbs, float v) {
+    const unsigned u = __float_as_uint(v);
+    const int ex = (int)((u >> 23) & 0xffu);
+    if (ex == 0) return;                                         // zero (denormals are flushed: < 2^-126)
+    unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
+    int s = ex - 150 + 60;                                       // bit position of the mantissa's LSB in the fixed-point number
+    if (s < 0) { m = (s > -24) ? (m >> (-s)) : 0ull; s = 0; }
+    if (s > 95) s = 95;                                          // |v| >= 2^59 (never a finite activation statistic): pinned, no limb 3
+    const int k = s / 40, r = s - k * 40;
+    const unsigned long long x = m << r;                         // < 2^63
+    unsigned long long lo = x & ((1ull << 40) - 1ull), hi = x >> 40;
+    if (u >> 31) { lo = 0ull - lo; hi = 0ull - hi; }             // two's complement: limbs are signed accumulators
+    if (lo) atomicAdd(limbs + k, lo);
+    if (hi) atomicAdd(limbs + k + 1, hi);                        // k == 2 => r <= 15 => hi == 0
 }
 
-// Called by ALL threads of the workgroup after it has issued the stat_store()s of its row.
-//   rows     [nrows][2][Cfull] fp32 rows of this sample;   this workgroup's slice = channels [c0, c0 + ncol)
-//   tot      [Cfull][2] fp64 totals of this sample (written for the slice by the last arriver)
-//   counter  arrival counter of (sample, slice); `expected` workgroups arrive per launch
-//   scratch  LDS, >= (NTHREADS / (2 * ncol / 4)) * 2 * ncol doubles is NOT required: sized as (NTHREADS * 4) doubles
-// ncol % 4 == 0.  Fold order: thread (row lane rl, column quad q) adds rows rl, rl + RL, ... in fp64; the RL lane
-// sums of a column are then added in lane order -- fixed for a given (nrows, ncol, NTHREADS).
-template <int NTHREADS>
-__device__ __forceinline__ void stats_arrive_and_fold(const float* rows, int nrows, int Cfull, int c0, int ncol,
-                                                      double* tot, int* counter, int expected, double* scratch) {
-    typedef float f32x4_ __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x;
-    int* const flag = reinterpret_cast<int*>(scratch);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) {
-        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (prev == expected - 1);
-        if (last) {
-            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drop this CU's stale lines of the rows
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *flag = last;
-    }
-    __syncthreads();
-    const int last = *flag;
-    __syncthreads();                                                 // flag is read before scratch is reused
-    if (!last) return;
-    const int nq = (2 * ncol) >> 2;                                  // column quads: [sum | sumsq] x ncol / 4
-    const int RL = NTHREADS / nq;                                    // row lanes
-    const int q = tid % nq, rl = tid / nq;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    if (rl < RL) {
-        const int which = (q * 4) / ncol, cc = q * 4 - which * ncol;
-        const float* p = rows + (size_t)which * Cfull + c0 + cc;
-        const size_t rstride = (size_t)2 * Cfull;
-        int r = rl;
-        for (; r + 3 * RL < nrows; r += 4 * RL) {                    // four independent 16-byte loads in flight
-            const f32x4_ v0 = *reinterpret_cast<const f32x4_*>(p + (size_t)r * rstride);
-            const f32x4_ v1 = *reinterpret_cast<const f32x4_*>(p + (size_t)(r + RL) * rstride);
-            const f32x4_ v2 = *reinterpret_cast<const f32x4_*>(p + (size_t)(r + 2 * RL) * rstride);
-            const f32x4_ v3 = *reinterpret_cast<const f32x4_*>(p + (size_t)(r + 3 * RL) * rstride);
-            a0 += (double)v0[0]; a1 += (double)v0[1]; a2 += (double)v0[2]; a3 += (double)v0[3];
-            a0 += (double)v1[0]; a1 += (double)v1[1]; a2 += (double)v1[2]; a3 += (double)v1[3];
-            a0 += (double)v2[0]; a1 += (double)v2[1]; a2 += (double)v2[2]; a3 += (double)v2[3];
-            a0 += (double)v3[0]; a1 += (double)v3[1]; a2 += (double)v3[2]; a3 += (double)v3[3];
-        }
-        for (; r < nrows; r += RL) {
-            const f32x4_ v = *reinterpret_cast<const f32x4_*>(p + (size_t)r * rstride);
-            a0 += (double)v[0]; a1 += (double)v[1]; a2 += (double)v[2]; a3 += (double)v[3];
-        }
-        double* s = scratch + ((size_t)rl * nq + q) * 4;
-        s[0] = a0; s[1] = a1; s[2] = a2; s[3] = a3;
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * ncol; i += NTHREADS) {                 // column i of [sum | sumsq]
-        double t = 0;
-        for (int l = 0; l < RL; ++l) t += scratch[(size_t)l * nq * 4 + i];
-        const int which = i / ncol, cc = i - which * ncol;
-        tot[(size_t)(c0 + cc) * 2 + which] = t;
-    }
+__device__ __forceinline__ double stat_total(const stat_word* limbs) {
+    const long long l0 = (long long)limbs[0], l1 = (long long)limbs[1], l2 = (long long)limbs[2];
+    return (double)l0 * 0x1p-60 + (double)l1 * 0x1p-20 + (double)l2 * 0x1p20;       // each limb is exact in fp64 (|l| < 2^53)
 }
-constexpr int stats_scratch_doubles(int nthreads) { return nthreads * 4; }
 
 // GroupNorm scale/shift of sample b into LDS: gnp[c] = mult * rstd * gamma[c], gnp[Cin + c] = mult * (beta[c] - mean * rstd * gamma[c]).
-// tot0 / tot1: per-channel fp64 (sum, sumsq) totals [B][C0][2] / [B][C1][2] of the two concatenated sources (tot1 may
-// be null when C1 == 0); hw = pixels per channel.  Wave w handles groups w, w + nwaves, ...: lane l loads channel
-// g*cg + l (+64, ...), a 64-lane butterfly (commutative adds: every lane ends with the same bits) gives the group
-// sums, mean / rstd in fp64.  Visible to the workgroup after its next barrier.  Called by all threads.
-__device__ __forceinline__ void gn_prologue_lds(const double* __restrict__ tot0, int C0, const double* __restrict__ tot1, int C1,
+// tot0 / tot1: totals [B][C0][2][3] / [B][C1][2][3] of the two concatenated sources (tot1 is not read when C1 == 0);
+// hw = pixels per channel.  Wave w handles groups w, w + nwaves, ...: lane l takes channel g*cg + l (+64, ...), a
+// 64-lane butterfly (commutative adds: every lane ends with the same bits) gives the group sums, mean / rstd in fp64.
+// Visible to the workgroup after its next barrier.  Called by all threads.
+__device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ tot0, int C0, const stat_word* __restrict__ tot1, int C1,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                 int hw, int b, float mult, float* gnp, int tid, int nthreads) {
     const int Cin = C0 + C1, cg = Cin / GN_GROUPS_C;
@@ -105,9 +61,8 @@ __device__ __forceinline__ void gn_prologue_lds(const double* __restrict__ tot0,
         double s1 = 0, s2 = 0;
         for (int l = lane; l < cg; l += 64) {
             const int c = g * cg + l;
-            const double* p = (c < C0) ? tot0 + ((size_t)b * C0 + c) * 2 : tot1 + ((size_t)b * C1 + (c - C0)) * 2;
-            const double2 v = *reinterpret_cast<const double2*>(p);
-            s1 += v.x; s2 += v.y;
+            const stat_word* p = (c < C0) ? tot0 + ((size_t)b * C0 + c) * STAT_WORDS : tot1 + ((size_t)b * C1 + (c - C0)) * STAT_WORDS;
+            s1 += stat_total(p); s2 += stat_total(p + STAT_LIMBS);
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }

@@ -306,10 +306,10 @@ def test_two_threads_two_streams_share_one_model():
 
 # ------------------------------------------------------------------------------ statistics hand-off inside a launch
 def test_statistics_are_never_stale_across_launches():
-    """The GroupNorm totals are folded by the last-arriving workgroup of the PRODUCING launch from rows other workgroups
-    stored write-through (csrc/stats_common.h).  A stale read of those rows would return the previous launch's values:
-    alternate two very different inputs through the same plan / workspace and require, bit for bit, the results of
-    fresh single runs."""
+    """The GroupNorm totals are accumulated with atomics into an arena that is cleared once per forward
+    (csrc/stats_common.h).  Anything left over from, or read before, another launch would show as a dependence on the
+    previous call: alternate two very different inputs through the same plan / workspace and require, bit for bit, the
+    results of fresh single runs."""
     cfg = UNetConfig()
     sd = make_state_dict(cfg, seed=42)
     model = _model({}, sd)
@@ -328,12 +328,12 @@ def test_statistics_are_never_stale_across_launches():
 
 def test_optional_kernels_are_reached():
     """Child-process helper of test_gpu_optional_paths.py: with an opt-in knob in the environment, the kernel it
-    selects must actually be launched on the shapes that test runs (full network, B = 4, 64x64 and 128x128)."""
+    selects must actually be launched on the shapes that test runs (full network, B = 4, 64x64 and 256x256)."""
     knobs = {k: os.environ.get(k) for k in ("MIDD_PREDMA_MAX_HW", "MIDD_TILE_BIG", "MIDD_TILE_NT6", "MIDD_CONV1X1_DIRECT")}
     cfg = UNetConfig()
     model = _model({}, make_state_dict(cfg, seed=42))
     names = set()
-    for size in (64, 128):
+    for size in (64, 256):
         x = torch.from_numpy(synthetic_xray(4, size, size, seed=5)).cuda()
         model.profile_begin()
         model(x, x, torch.full((4,), 7, dtype=torch.long))

@@ -1,6 +1,7 @@
 """Per-op timing of one sampler iteration (MIDD_PROFILE_PER_OP=1): python tools/per_op_profile.py [B] [size]"""
 import os, sys
 os.environ["MIDD_PROFILE_PER_OP"] = "1"
+os.environ.setdefault("MIDD_SPLIT", "1")      # one stream: spans are per-kernel times, not contended ones
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
