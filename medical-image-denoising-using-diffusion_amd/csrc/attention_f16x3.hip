@@ -365,7 +365,7 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
     if (e != hipSuccess) return e;
     // split the keys until ~512 workgroups exist (two per CU), keeping at least two 32-key tiles per split
     const int qblocks = (N + A16_QB - 1) / A16_QB, tiles = (N + A16_KT - 1) / A16_KT;
-    static const int want_wgs = getenv("MIDD_ATT_WGS") ? atoi(getenv("MIDD_ATT_WGS")) : 384;
+    static const int want_wgs = getenv("MIDD_ATT_WGS") ? atoi(getenv("MIDD_ATT_WGS")) : 256;
     int ksplit = 1;
     while ((long)qblocks * heads * B * ksplit < want_wgs && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
     const int tps = (tiles + ksplit - 1) / ksplit;

@@ -57,6 +57,51 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
                                                 int hw, int b, float mult, float* gnp, int tid, int nthreads) {
     const int Cin = C0 + C1, cg = Cin / GN_GROUPS_C;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    if (cg <= 64 && GN_GROUPS_C <= 2 * nwaves) {
+        // common case: at most two groups per wave, one channel per lane.  Every load (totals live at the memory
+        // side after the producers' atomics: ~1 us away; gamma / beta) is requested before any of them is used.
+        const int g0 = wave, g1 = wave + nwaves;
+        const bool on0 = g0 < GN_GROUPS_C && lane < cg, on1 = g1 < GN_GROUPS_C && lane < cg;
+        const int c0 = g0 * cg + lane, c1 = g1 * cg + lane;
+        stat_word w0[STAT_WORDS], w1[STAT_WORDS];
+        float ga0 = 0.f, be0 = 0.f, ga1 = 0.f, be1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < STAT_WORDS; ++i) { w0[i] = 0; w1[i] = 0; }
+        if (on0) {
+            const stat_word* p = (c0 < C0) ? tot0 + ((size_t)b * C0 + c0) * STAT_WORDS : tot1 + ((size_t)b * C1 + (c0 - C0)) * STAT_WORDS;
+#pragma unroll
+            for (int i = 0; i < STAT_WORDS; ++i) w0[i] = p[i];
+            ga0 = gamma[c0]; be0 = beta[c0];
+        }
+        if (on1) {
+            const stat_word* p = (c1 < C0) ? tot0 + ((size_t)b * C0 + c1) * STAT_WORDS : tot1 + ((size_t)b * C1 + (c1 - C0)) * STAT_WORDS;
+#pragma unroll
+            for (int i = 0; i < STAT_WORDS; ++i) w1[i] = p[i];
+            ga1 = gamma[c1]; be1 = beta[c1];
+        }
+        double s1a = stat_total(w0), s2a = stat_total(w0 + STAT_LIMBS), s1b = stat_total(w1), s2b = stat_total(w1 + STAT_LIMBS);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            s1a += __shfl_xor(s1a, off, 64); s2a += __shfl_xor(s2a, off, 64);
+            s1b += __shfl_xor(s1b, off, 64); s2b += __shfl_xor(s2b, off, 64);
+        }
+        const double n = (double)hw * cg;
+        {
+            const double mean = s1a / n;
+            double var = s2a / n - mean * mean;              // biased variance, as torch's group_norm
+            if (var < 0) var = 0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+            if (on0) { const float sc = rstd * ga0; gnp[c0] = mult * sc; gnp[Cin + c0] = mult * (be0 - meanf * sc); }
+        }
+        if (g1 < GN_GROUPS_C) {
+            const double mean = s1b / n;
+            double var = s2b / n - mean * mean;
+            if (var < 0) var = 0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+            if (on1) { const float sc = rstd * ga1; gnp[c1] = mult * sc; gnp[Cin + c1] = mult * (be1 - meanf * sc); }
+        }
+        return;
+    }
     for (int g = wave; g < GN_GROUPS_C; g += nwaves) {
         double s1 = 0, s2 = 0;
         for (int l = lane; l < cg; l += 64) {
