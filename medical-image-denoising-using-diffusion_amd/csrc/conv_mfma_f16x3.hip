@@ -150,21 +150,14 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int nchunks = (nblk + CB - 1) / CB;
     const int ntiles_total = a.Cout >> 4;
     const int ntile_wg = blockIdx.y * (WN * NT);          // first cout tile of this workgroup
-    // Split-K (a.chunks_per_split > 0, 16-channel chunks only): blockIdx.z owns the chunks [c_begin, c_end) of every
-    // tile it walks and leaves out_scale * (its partial sum) in a.partial[z]; splitk_finish_kernel adds the slices in
-    // z order, then bias / time embedding / residual / statistics.  Gives the latency-bound small maps (one
-    // workgroup per CU and 100-step K loops at 32x32) several co-resident workgroups with short K loops instead.
-    const int c_begin = (a.chunks_per_split > 0) ? (int)blockIdx.z * a.chunks_per_split : 0;
-    const int c_end = (a.chunks_per_split > 0) ? min(nchunks, c_begin + a.chunks_per_split) : nchunks;
-    const int first_step = c_begin * ((TAPS + 1) / 2);                             // (CB == 1 when splitting)
-    const int total_steps = (a.chunks_per_split > 0) ? (c_end - c_begin) * ((TAPS + 1) / 2) : conv16_num_steps(Cin, TAPS);
+    const int total_steps = conv16_num_steps(Cin, TAPS);
 
     // ---- weights: LDS-DMA ring ---------------------------------------------------------------
     // global layout [step][cout tile][hi|lo][lane] x 16 B; the workgroup's slice of one step is
     // contiguous.  Everything but the lane offset is wave-uniform, so the address arithmetic stays
     // on the scalar unit.
+    const char* const wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048;
     const size_t wstep_bytes = (size_t)ntiles_total * 2048;
-    const char* const wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048 + (size_t)first_step * wstep_bytes;
     const int lane16 = lane * 16;
     int wr_step = 0, wr_slot = 0;                         // next step to fetch / the ring slot it goes to
     const char* wr_src = wbase;                           // = wbase + wr_step * wstep_bytes, kept incrementally
@@ -289,7 +282,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     constexpr int D = RING - 1;
     const int ntile0 = ntile_wg + wn * NT;
     TS_DECL
-    issue_a(c_begin);
+    issue_a(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
     if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
@@ -303,7 +296,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         }
     }
     wait_vm_and_barrier<0>();               // everything above has landed / is visible (once per launch)
-    transform(c_begin);
+    transform(0);
     if constexpr (WM == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -397,14 +390,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 const int oy = oy0 + py, ox = ox0 + px;
                 if (oy < a.OH && ox < a.OW) {
                     const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
-                    if (a.partial != nullptr) {          // split-K slice: the raw partial sum, finished by splitk_finish_kernel
-                        *reinterpret_cast<f32x4*>(a.partial + (size_t)blockIdx.z * a.partial_stride + o) = acc[mt][nt] * a.out_scale;
-                    } else {
-                        f32x4 v = acc[mt][nt] * a.out_scale + add;
-                        if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-                        *reinterpret_cast<f32x4*>(a.out + o) = v;
-                        tsum[nt] += v; tsq[nt] += v * v;
-                    }
+                    f32x4 v = acc[mt][nt] * a.out_scale + add;
+                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+                    *reinterpret_cast<f32x4*>(a.out + o) = v;
+                    tsum[nt] += v; tsq[nt] += v * v;
                 }
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -446,10 +435,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     for (;;) {
         const int next_tile = trem + a.wgs_per_img;
         const bool has_next_tile = next_tile < tiles_per_img;
-        for (int c = c_begin; c < c_end; ++c) {
-            const bool more_in_tile = (c + 1 < c_end);
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more_in_tile = (c + 1 < nchunks);
             const bool more = more_in_tile || has_next_tile;
-            const int next_chunk = more_in_tile ? c + 1 : c_begin;
+            const int next_chunk = more_in_tile ? c + 1 : 0;
             const bool full = (CB == 2) && (2 * c + 1 < nblk);
             // the staging geometry switches to the next tile right before its first chunk is requested
             // (every transform of the current tile is done by then; the epilogue does not use it)
@@ -561,14 +550,8 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + G::TH - 1) / G::TH;
     const int ny = a.Cout / (WN * NT * 16);
-    int nz = 1;
-    if (a.chunks_per_split > 0) {
-        if (G::CB != 1 || a.partial == nullptr) return hipErrorInvalidValue;
-        const int nchunks = (a.C0 + a.C1) / 16;
-        nz = (nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    }
-    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B * nz, ny, a.persist_wgs);
-    dim3 grid(a.B * a.wgs_per_img, ny, nz);
+    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny, a.persist_wgs);
+    dim3 grid(a.B * a.wgs_per_img, ny);
 #ifdef MIDD_CONV_TIMING
     a.dbg_slot = conv_timing_slot(KS, STRIDE, TW, MT, NT, WM, WN, a.OH, a.C0 + a.C1, a.Cout, a.B, G::RING, (int)grid.x * (int)grid.y);
 #endif

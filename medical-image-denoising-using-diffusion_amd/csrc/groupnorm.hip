@@ -66,63 +66,6 @@ hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, in
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------ split-K finish
-// grid (rows, B), thread = (pixel lane, channel quad) like chan_total_kernel: adds the K slices of a split convolution
-// in slice order, then bias (+ time embedding) (+ residual) -- the epilogue of conv_mfma_f16x3.hip -- stores the
-// tensor and accumulates its GroupNorm totals.
-__global__ __launch_bounds__(GN_THREADS)
-void splitk_finish_kernel(const SplitKFinishArgs a) {
-    extern __shared__ double red[];               // [ppi][C][2]
-    const int C = a.C, CQ = C >> 2;
-    const int ppi = GN_THREADS / CQ;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.y, row = blockIdx.x, rows = gridDim.x;
-    const int pl = tid / CQ, q = tid - pl * CQ;
-    const int per = (a.HW + rows - 1) / rows;
-    const int p0 = row * per, p1 = min(a.HW, p0 + per);
-    if (pl < ppi) {
-        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-        f32x4 add = *reinterpret_cast<const f32x4*>(a.bias + q * 4);
-        if (a.temb != nullptr) add += *reinterpret_cast<const f32x4*>(a.temb + (size_t)a.trow[b] * a.temb_stride + q * 4);
-        for (int p = p0 + pl; p < p1; p += ppi) {
-            const size_t o = ((size_t)b * a.HW + p) * C + q * 4;
-            f32x4 v = *reinterpret_cast<const f32x4*>(a.partial + o);
-            for (int z = 1; z < a.nsplit; ++z) v += *reinterpret_cast<const f32x4*>(a.partial + (size_t)z * a.partial_stride + o);
-            v += add;
-            if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-            *reinterpret_cast<f32x4*>(a.out + o) = v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; ss[e] = fma(d, d, ss[e]); }
-        }
-        if (a.stat_tot != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                red[((size_t)pl * C + q * 4 + e) * 2 + 0] = s[e];
-                red[((size_t)pl * C + q * 4 + e) * 2 + 1] = ss[e];
-            }
-        }
-    }
-    if (a.stat_tot == nullptr) return;
-    __syncthreads();
-    for (int c = tid; c < C; c += GN_THREADS) {
-        double cs = 0, css = 0;
-        for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
-        stat_word* o = a.stat_tot + ((size_t)b * C + c) * STAT_WORDS;
-        stat_atomic_add(o, (float)cs); stat_atomic_add(o + STAT_LIMBS, (float)css);
-    }
-}
-
-hipError_t splitk_finish_launch(const SplitKFinishArgs& a, hipStream_t s) {
-    if (a.C % 4 || a.C / 4 > GN_THREADS || a.nsplit < 1) return hipErrorInvalidValue;
-    const int ppi = GN_THREADS / (a.C / 4);
-    int rows = a.HW / (ppi * 2);                  // >= 2 pixels per lane row: enough blocks for a memory-bound pass over small maps
-    if (rows < 1) rows = 1;
-    if (rows > 256) rows = 256;
-    const size_t lds = (size_t)ppi * a.C * 2 * sizeof(double);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(rows, a.B), dim3(GN_THREADS), lds, s, a);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------ pre-activation pass (opt-in)
 // grid (chunks, B).  One thread = 4 channels of one pixel.  Same arithmetic as the conv's in-kernel transform
 // (conv_mfma_f16x3.hip): v = x * (16 sc) + 16 sh, SiLU on the 16x-scaled value, hi = fp16(v), lo = fp16(v - hi); output

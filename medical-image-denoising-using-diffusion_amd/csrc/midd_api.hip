@@ -64,7 +64,7 @@ struct TensorRef {
 
 struct GnRef { size_t gamma = 0, beta = 0; bool on = false; };        // affine of the GroupNorm in front of a consumer
 
-enum OpKind { OP_IN_CONV, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_TOT, OP_PREACT, OP_SPLITK_FINISH };
+enum OpKind { OP_IN_CONV, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_TOT, OP_PREACT };
 struct Op {
     OpKind kind;
     // sources / destination (workspace offsets in bytes)
@@ -80,8 +80,6 @@ struct Op {
     int stride = 1, ks = 3;
     bool want_stats = false;
     float out_scale = 1.f;
-    int ksplit = 1, cps = 0;    // OP_CONV / OP_SPLITK_FINISH: K slices, 16-channel chunks per slice
-    size_t split_off = 0;       // ... their partial sums [ksplit][B][OH][OW][Cout]
 };
 
 struct Program {
@@ -621,27 +619,7 @@ struct Builder {
         }
         if (want_stats) { alloc_stats(dst); o.want_stats = true; }
         o.dst = dst;
-        // Split-K for launches that cannot fill the chip (small maps, small batches): K slices in blockIdx.z, partial
-        // sums in the workspace, finished (slice order, bias / temb / residual / statistics) by splitk_finish_kernel.
-        static const long split_below = getenv("MIDD_SPLITK_BELOW") ? atol(getenv("MIDD_SPLITK_BELOW")) : 400;
-        static const long split_target = getenv("MIDD_SPLITK_TARGET") ? atol(getenv("MIDD_SPLITK_TARGET")) : 640;
-        if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && ks == 3 && o.prologue != PRO_PRE_DMA && o.tile.tw != 0) {
-            const int nchunks = (s0.C + (s1 ? s1->C : 0)) / 16;
-            const int th = o.tile.wm * o.tile.mt * 16 / o.tile.tw;
-            const long wgs = (long)B * ((dst.W + o.tile.tw - 1) / o.tile.tw) * ((dst.H + th - 1) / th) * (dst.C / (o.tile.wn * o.tile.nt * 16));
-            if (wgs < split_below && nchunks >= 4) {
-                long want = (split_target + wgs - 1) / wgs;
-                if (want > nchunks / 2) want = nchunks / 2;
-                if (want > 8) want = 8;
-                if (want >= 2) {
-                    o.cps = (int)((nchunks + want - 1) / want);
-                    o.ksplit = (nchunks + o.cps - 1) / o.cps;
-                    o.split_off = bump.take((size_t)o.ksplit * B * dst.H * dst.W * dst.C * sizeof(float));
-                }
-            }
-        }
         g->ops.push_back(o);
-        if (o.ksplit > 1) { Op f = o; f.kind = OP_SPLITK_FINISH; g->ops.push_back(f); }
         return MI_OK;
     }
 };
@@ -824,7 +802,6 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             *bytes = 4.0 * (2.0 * B * p->cfg.in_channels * g->H * g->W + elems(o.dst));
             break;
         case OP_CHAN_TOT: *name = "midd::chan_total_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
-        case OP_SPLITK_FINISH: *name = "midd::splitk_finish_kernel"; *flops = 0; *bytes = 4.0 * elems(o.dst) * (o.ksplit + 1 + (o.has_resid ? 1 : 0)); break;
         case OP_PREACT: *name = "midd::preact_kernel"; *flops = 0; *bytes = 8.0 * elems(o.dst); break;
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
@@ -918,23 +895,8 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
                 a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;
                 if (o.want_stats) a.stat_tot = T(o.dst.tot_off);
-                if (o.ksplit > 1) {            // K slices: raw partial sums only; OP_SPLITK_FINISH does the epilogue
-                    a.partial = F(o.split_off); a.partial_stride = (size_t)B * o.dst.H * o.dst.W * o.dst.C; a.chunks_per_split = o.cps;
-                    a.stat_tot = nullptr; a.resid = nullptr;
-                }
                 a.persist_wgs = g->persist_wgs;
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
-                break;
-            }
-            case OP_SPLITK_FINISH: {
-                SplitKFinishArgs a{};
-                a.partial = F(o.split_off); a.partial_stride = (size_t)B * o.dst.H * o.dst.W * o.dst.C; a.nsplit = o.ksplit;
-                a.bias = wd + o.b;
-                if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
-                a.resid = o.has_resid ? F(o.resid.off) : nullptr;
-                a.out = F(o.dst.off); a.stat_tot = o.want_stats ? T(o.dst.tot_off) : nullptr;
-                a.B = B; a.HW = o.dst.H * o.dst.W; a.C = o.dst.C;
-                e = splitk_finish_launch(a, s);
                 break;
             }
             case OP_ATTN:

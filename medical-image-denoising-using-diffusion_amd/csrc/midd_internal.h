@@ -34,9 +34,6 @@ struct ConvArgs {
     const int* trow;        // [B] table row per sample
     const float* resid;     // NHWC [B][OH][OW][Cout] added in the epilogue, or null
     float* out;             // NHWC [B][OH][OW][Cout]
-    // f16x3 3x3 kernel, split-K: slice z (blockIdx.z) covers 16-channel chunks [z*chunks_per_split, ...) and writes its
-    // partial sums to partial + z*partial_stride ([B][OH][OW][Cout] each); 0 / null = no split
-    float* partial; size_t partial_stride; int chunks_per_split;
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     const float* zeros;     // (unused) 64 zero floats
     // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
@@ -145,15 +142,6 @@ struct StepSched { float c1, c2, c3; int t; int use_noise; int pad[3]; };
 // trow[b] = sched[*counter].t for all b  /  ++*counter   (first and last node of a captured forward)
 hipError_t step_begin_launch(const StepSched* sched, const int* counter, int* trow, int B, hipStream_t s);
 hipError_t step_end_launch(int* counter, hipStream_t s);
-
-// out = sum_z partial[z] + bias (+ temb row) (+ resid); per-channel totals of out -> stat_tot (split-K convolutions)
-struct SplitKFinishArgs {
-    const float* partial; size_t partial_stride; int nsplit;
-    const float* bias; const float* temb; int temb_stride; const int* trow;
-    const float* resid; float* out; stat_word* stat_tot;
-    int B, HW, C;
-};
-hipError_t splitk_finish_launch(const SplitKFinishArgs& a, hipStream_t s);
 
 // bilinear resize NHWC (align_corners=False), any size ratio
 hipError_t resize_bilinear_launch(const float* src, float* dst, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
