@@ -73,6 +73,8 @@ struct Op {
     GnRef gn;                   // OP_CONV / OP_PREACT / OP_OUT: GroupNorm of (s0, s1) applied while staging
     size_t partial_off = 0;     // OP_ATTN: pre-split K / V^T scratch
     int stat_rows = 0;          // OP_CHAN_TOT: blocks per sample
+    bool on_side = false;       // runs on the part's branch stream, next to the ops that follow it (res_conv next to conv1)
+    bool joins_side = false;    // first op that needs the branch's result
     // OP_CONV
     size_t w = 0, b = 0;
     int prologue = PRO_RAW, temb_col = -1;
@@ -117,6 +119,10 @@ struct mi_plan {
     hipEvent_t sev_fork = nullptr, sev_phase[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr},
                sev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex side_mu;
+    // per part: a branch stream for ops that only depend on the block input (ResidualBlock.res_conv runs beside conv1:
+    // DDIMModel.py:126,133) + fork / join events
+    struct Branch { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    Branch branch[MAX_PARTS];
     // profiling (mi_profile_begin/end)
     bool profiling = false;
     struct Span { hipEvent_t a, b; std::string name; double flops, bytes; };
@@ -641,13 +647,20 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         const int cin = s0.C + (s1 ? s1->C : 0);
         if (cin != m.in_c) return fail(MI_EINVAL, "%s: expected %d input channels, graph provides %d", m.name.c_str(), m.in_c, cin);
         TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
-        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
-        const GnRef g2{m.g2, m.be2, true};
         TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
+        // res_conv(x) needs nothing but the block input: it is issued first, on the part's branch stream, and runs
+        // beside conv1; conv2 (which adds it in place) is the join
+        static const bool branch_on = !(getenv("MIDD_BRANCH") && atoi(getenv("MIDD_BRANCH")) == 0);
         if (m.in_c != m.out_c) {
             if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, no_gn, -1, nullptr, false))) return rc;   // res_conv(x)
+            g->ops.back().on_side = branch_on;
+        }
+        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
+        const GnRef g2{m.g2, m.be2, true};
+        if (m.in_c != m.out_c) {
             const TensorRef acc = o;
             if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &acc, true))) return rc;   // + in place
+            g->ops.back().joins_side = branch_on;
         } else {
             if (s1) return fail(MI_EINVAL, "%s: identity residual over a concatenated input", m.name.c_str());
             if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &s0, true))) return rc;
@@ -840,17 +853,44 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
     }
 }
 
-static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s,
+static int ensure_branch(mi_plan* p, int part) {
+    mi_plan::Branch& br = p->branch[part];
+    if (br.stream) return MI_OK;
+    HIPCHK(hipStreamCreateWithFlags(&br.stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&br.fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&br.join, hipEventDisableTiming));
+    return MI_OK;
+}
+
+// Callers hold plan->side_mu: the branch streams / events are per plan.
+static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s_main, int part = 0,
                        hipEvent_t mid_event = nullptr, int mid_div = 2) {
+    if (int rcb = ensure_branch(p, part)) return rcb;
+    const mi_plan::Branch& br = p->branch[part];
+    bool side_pending = false;              // a branch kernel has been issued and not yet joined
+    struct JoinGuard {                      // whatever happens below, the caller's stream ends up behind the branch
+        const mi_plan::Branch& br; hipStream_t s; bool& pending;
+        ~JoinGuard() { if (pending && (hipEventRecord(br.join, br.stream) != hipSuccess || hipStreamWaitEvent(s, br.join, 0) != hipSuccess)) (void)hipStreamSynchronize(br.stream); }
+    } guard{br, s_main, side_pending};
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
     auto T = [&](size_t off) { return reinterpret_cast<stat_word*>(ws + off); };
     // every tensor's GroupNorm totals start the forward at zero (producers accumulate with atomics)
-    if (hipMemsetAsync(ws + g->stats_off, 0, g->stats_bytes, s) != hipSuccess) return fail(MI_EHIP, "clearing the statistics arena failed");
+    if (hipMemsetAsync(ws + g->stats_off, 0, g->stats_bytes, s_main) != hipSuccess) return fail(MI_EHIP, "clearing the statistics arena failed");
     for (const Op& o : g->ops) {
         hipError_t e = hipSuccess;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
+        hipStream_t s = s_main;
+        if (o.on_side) {                    // fork: the branch starts where the main stream is now
+            if (hipEventRecord(br.fork, s_main) != hipSuccess || hipStreamWaitEvent(br.stream, br.fork, 0) != hipSuccess)
+                return fail(MI_EHIP, "branch fork failed");
+            s = br.stream;
+        } else if (o.joins_side && side_pending) {
+            if (hipEventRecord(br.join, br.stream) != hipSuccess || hipStreamWaitEvent(s_main, br.join, 0) != hipSuccess)
+                return fail(MI_EHIP, "branch join failed");
+            side_pending = false;
+        }
         if (p->profiling) {
             auto take = [&]() -> hipEvent_t {
                 hipEvent_t ev = nullptr;
@@ -927,9 +967,10 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             }
         }
         if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
+        if (o.on_side) side_pending = true;
         static const int phase_pct = getenv("MIDD_PHASE_PCT") ? atoi(getenv("MIDD_PHASE_PCT")) : 0;
         const size_t mid_at = phase_pct ? g->ops.size() * phase_pct / 100 : g->ops.size() / mid_div;
-        if (mid_event && (size_t)(&o - g->ops.data()) == mid_at) (void)hipEventRecord(mid_event, s);
+        if (mid_event && (size_t)(&o - g->ops.data()) == mid_at) (void)hipEventRecord(mid_event, s_main);
         if (p->profiling) {
             (void)hipEventRecord(ev_b, s);
             mi_plan::Span sp; sp.a = ev_a; sp.b = ev_b;
@@ -972,6 +1013,7 @@ extern "C" int mi_unet_forward(mi_plan* plan, const float* x, const float* condi
     hipError_t e = fill_i32_launch(reinterpret_cast<int*>(ws + g->trow_off), t, B, s);
     if (e != hipSuccess) return fail(MI_EHIP, "fill timesteps: %s", hipGetErrorString(e));
     StepIO io{x, condition, eps, nullptr, nullptr, 0.f, 0.f, 0.f, 0};
+    std::lock_guard<std::mutex> lk(plan->side_mu);
     return run_program(plan, g, io, ws, s);
 }
 
@@ -1050,6 +1092,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const size_t img_elems = (size_t)B * plan->cfg.in_channels * H * W;
+    std::lock_guard<std::mutex> side_lk(plan->side_mu);      // the side / branch streams and their events are per plan: one enqueue at a time
     // fp32 arithmetic in the reference's order (DDIMModel.py:280-283)
     auto coef = [&](int t, float* c1, float* c2, float* c3) {
         *c1 = 1.0f / sqrtf(alpha[t]);
@@ -1073,7 +1116,6 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         Program* gh = nullptr;
         if ((rc = get_program(plan, B / parts, H, W, &gh, true))) return rc;
         if (workspace_bytes < parts * gh->bytes) return fail(MI_ENOMEM, "workspace too small for the split run: need %zu bytes", parts * gh->bytes);
-        std::lock_guard<std::mutex> lk(plan->side_mu);
         if (!plan->sev_fork) HIPCHK(hipEventCreateWithFlags(&plan->sev_fork, hipEventDisableTiming));
         for (int h = 1; h < parts; ++h) {
             if (!plan->sstream[h]) {
@@ -1101,7 +1143,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
                     io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
                     if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
                     hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
-                    int rc2 = run_program(plan, gh, io, wsh, sh, mid, parts);
+                    int rc2 = run_program(plan, gh, io, wsh, sh, h, mid, parts);
                     if (rc2) return rc2;
                 }
             }
@@ -1191,6 +1233,11 @@ extern "C" void mi_plan_destroy(mi_plan* plan) {
     if (plan->gev_in) (void)hipEventDestroy(plan->gev_in);
     if (plan->gev_out) (void)hipEventDestroy(plan->gev_out);
     if (plan->gstream) (void)hipStreamDestroy(plan->gstream);
+    for (auto& br : plan->branch) {
+        if (br.fork) (void)hipEventDestroy(br.fork);
+        if (br.join) (void)hipEventDestroy(br.join);
+        if (br.stream) (void)hipStreamDestroy(br.stream);
+    }
     if (plan->sev_fork) (void)hipEventDestroy(plan->sev_fork);
     for (int i = 0; i < mi_plan::MAX_PARTS; ++i) {
         if (plan->sev_phase[i]) (void)hipEventDestroy(plan->sev_phase[i]);

@@ -42,6 +42,14 @@ __device__ __forceinline__ void stat_atomic_add(stat_word* limbs, float v) {
     if (hi) atomicAdd(limbs + k + 1, hi);                        // k == 2 => r <= 15 => hi == 0
 }
 
+// 1 / sqrt(x) to fp32 accuracy without the fp64 sqrt / divide sequence: v_rsq_f32 and one Newton step
+__device__ __forceinline__ float stat_rstd(double var_plus_eps) {
+    const float x = (float)var_plus_eps;
+    float y = __builtin_amdgcn_rsqf(x);
+    y = y * (1.5f - 0.5f * x * y * y);
+    return y;
+}
+
 __device__ __forceinline__ double stat_total(const stat_word* limbs) {
     const long long l0 = (long long)limbs[0], l1 = (long long)limbs[1], l2 = (long long)limbs[2];
     return (double)l0 * 0x1p-60 + (double)l1 * 0x1p-20 + (double)l2 * 0x1p20;       // each limb is exact in fp64 (|l| < 2^53)
@@ -85,19 +93,19 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
             s1a += __shfl_xor(s1a, off, 64); s2a += __shfl_xor(s2a, off, 64);
             s1b += __shfl_xor(s1b, off, 64); s2b += __shfl_xor(s2b, off, 64);
         }
-        const double n = (double)hw * cg;
+        const double inv_n = 1.0 / ((double)hw * cg);
         {
-            const double mean = s1a / n;
-            double var = s2a / n - mean * mean;              // biased variance, as torch's group_norm
+            const double mean = s1a * inv_n;
+            double var = s2a * inv_n - mean * mean;          // biased variance, as torch's group_norm
             if (var < 0) var = 0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+            const float rstd = stat_rstd(var + (double)eps), meanf = (float)mean;
             if (on0) { const float sc = rstd * ga0; gnp[c0] = mult * sc; gnp[Cin + c0] = mult * (be0 - meanf * sc); }
         }
         if (g1 < GN_GROUPS_C) {
-            const double mean = s1b / n;
-            double var = s2b / n - mean * mean;
+            const double mean = s1b * inv_n;
+            double var = s2b * inv_n - mean * mean;
             if (var < 0) var = 0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps)), meanf = (float)mean;
+            const float rstd = stat_rstd(var + (double)eps), meanf = (float)mean;
             if (on1) { const float sc = rstd * ga1; gnp[c1] = mult * sc; gnp[Cin + c1] = mult * (be1 - meanf * sc); }
         }
         return;
@@ -111,11 +119,11 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-        const double n = (double)hw * cg;
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;               // biased variance, as torch's group_norm
+        const double inv_n = 1.0 / ((double)hw * cg);
+        const double mean = s1 * inv_n;
+        double var = s2 * inv_n - mean * mean;           // biased variance, as torch's group_norm
         if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float rstd = stat_rstd(var + (double)eps);
         const float meanf = (float)mean;
         for (int l = lane; l < cg; l += 64) {
             const int c = g * cg + l;
