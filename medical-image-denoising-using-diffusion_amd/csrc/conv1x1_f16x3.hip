@@ -249,12 +249,10 @@ static hipError_t launch1(const ConvArgs& a0, hipStream_t s) {
 
 // tile.tw == 0 marks the flattened-pixel 1x1 kernel (tile = 64*mt pixels x 16*nt couts, 4 waves)
 bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t) {
-    static const int enabled = getenv("MIDD_CONV1X1_DIRECT") ? atoi(getenv("MIDD_CONV1X1_DIRECT")) : 1;
-    if (!enabled || Cout % 16 || Cin % 16) return false;
+    if (Cout % 16 || Cin % 16) return false;
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const long wgs2 = (long)B * ((OH * OW + 127) / 128) * (Cout / (16 * nt));
-    static const long mt2_wgs = getenv("MIDD_C1_MT2_WGS") ? atol(getenv("MIDD_C1_MT2_WGS")) : 512;
-    const int mt = wgs2 >= mt2_wgs ? 2 : 1;                  // small maps: 64-pixel tiles, twice the workgroups
+    const int mt = wgs2 >= 512 ? 2 : 1;                      // small maps: 64-pixel tiles, twice the workgroups
     if (((Cin + 31) / 32) * nt * 2048 + 8 * Cin + 4096 > 150 * 1024) return false;   // all weights must fit in LDS
     *t = ConvTile{1, 1, 0, mt, nt, 4, 1};
     return true;

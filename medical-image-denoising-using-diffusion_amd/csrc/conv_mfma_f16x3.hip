@@ -75,9 +75,8 @@ struct Conv16Geom {
 #ifndef MIDD_RING_MAX
 #define MIDD_RING_MAX 6
 #endif
-    // 52 KB: three workgroups per CU; the wide (NT = 6) tile trades one resident workgroup for twice the
-    // MFMA work per staged activation, per barrier and per DMA group
-    static constexpr int LDS_TARGET = ((NT > 3 || MT > 2) ? 80 : MIDD_LDS_TARGET_KB) * 1024;
+    // 52 KB: three workgroups per CU
+    static constexpr int LDS_TARGET = MIDD_LDS_TARGET_KB * 1024;
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;                 // at NOMINAL_CIN
@@ -110,7 +109,7 @@ template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 #endif
 // the register budget is capped so that as many workgroups as the LDS target allows are resident
 // (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? ((NT > 3 || MT > 2) ? 2 : MIDD_CONV16_WAVES_PER_SIMD) : 1)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? MIDD_CONV16_WAVES_PER_SIMD : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
@@ -211,10 +210,16 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             dma16(base + byte_off, raw + (wave + s * NW) * 1024);
         }
     };
-    auto transform = [&](int c) {
+    // The transform of a chunk = per slot: read the raw fp32 quad, GroupNorm-apply (+SiLU), 2^s prescale, hi/lo split
+    // (transform_slot: LDS read + VALU only, result in registers) and the write into the MFMA image (commit_slot).
+    // 3x3 kernels (EARLY_T) run the transform_slot part of chunk c+1 UNDER the MFMAs of chunk c's later steps -- the
+    // raw chunk lands during steps 0-1 -- and only the commits at the chunk boundary, where the whole transform used
+    // to sit (12-28 % of a workgroup's cycles, in-kernel stamps); 1x1 chunks are one or two steps long and keep it there.
+    constexpr bool EARLY_T = (KS == 3);
+    half4 t_hi[APW], t_lo[APW];
+    auto transform_slot = [&](int c, int s) {
         const int blk = CB * c + sblk;
-        if (blk >= nblk) return;
-        const int ch = (blk << 4) + (q8 & 3) * 4;
+        const int ch = (min(blk, nblk - 1) << 4) + (q8 & 3) * 4;
         // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
         // raw operands (stride-2, folded ConvT, res_conv: not bounded by a GroupNorm) are split unscaled, so the
         // whole fp16 range (|x| < 65504) is available to them; normalised ones carry 2^s = 16
@@ -223,31 +228,36 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
             sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch) * ACT_PRESCALE;
         }
-        char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
+        const int slot = tid + s * NTHREADS;
+        f32x4 v = *reinterpret_cast<const f32x4*>(raw + (g_off[s] > -2 ? slot : tid) * 16);
+        v = v * sc + sh;
+        if (a.prologue == PRO_GN_SILU) {
 #pragma unroll
-        for (int s = 0; s < APW; ++s) {
-            const int slot = tid + s * NTHREADS;
-            if (g_off[s] > -2) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(raw + slot * 16);
-                v = v * sc + sh;
-                if (a.prologue == PRO_GN_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
-                        v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
-                }
-                if (g_off[s] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // the conv pads its (normalised) input with zeros
-                half4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const _Float16 h = (_Float16)v[e];
-                    hi[e] = h;
-                    lo[e] = (_Float16)(v[e] - (float)h);
-                }
-                const int pix = slot / QPP;
-                *reinterpret_cast<half4*>(base + pix * 32) = hi;
-                *reinterpret_cast<half4*>(base + PLANE + pix * 32) = lo;
-            }
+            for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
+                v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
         }
+        if (g_off[s] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // the conv pads its (normalised) input with zeros
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 h = (_Float16)v[e];
+            t_hi[s][e] = h;
+            t_lo[s][e] = (_Float16)(v[e] - (float)h);
+        }
+    };
+    auto commit_slot = [&](int c, int s) {
+        if (CB * c + sblk >= nblk || g_off[s] <= -2) return;
+        const int pix = (tid + s * NTHREADS) / QPP;
+        char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8 + pix * 32;
+        *reinterpret_cast<half4*>(base) = t_hi[s];
+        *reinterpret_cast<half4*>(base + PLANE) = t_lo[s];
+    };
+    auto transform = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < APW; ++s) { transform_slot(c, s); commit_slot(c, s); }
+    };
+    auto commit = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < APW; ++s) commit_slot(c, s);
     };
 
     // ---- per-lane LDS byte offsets of the B fragments (tap (0,0), block 0, hi plane) ----
@@ -343,9 +353,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // boundary), not on the step's barrier: they are requested first, so their LDS latency overlaps the wait.
     // `first` = first step of a chunk: its barrier is also the one that publishes the freshly transformed
     // image, so the fragments are read after it (WM == 1 has a dedicated barrier after the transform).
-    auto k_step = [&](auto with_a, bool first, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
+    // `wgroups` = weight groups that may still be in flight at this step's wait (normally D-1; fewer once the next
+    // raw chunk, issued in step 0 behind that step's refill, has to have landed: EARLY_T, steps >= 2)
+    auto k_step = [&](auto with_a, auto wgroups, bool first, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
         constexpr bool WITH_A = decltype(with_a)::value;
-        constexpr int N = (D - 1) * PPW + (WITH_A ? APW : 0);
+        constexpr int N = decltype(wgroups)::value * PPW + (WITH_A ? APW : 0);
         const bool early = (WM == 1) || !first;
         if (early) {
             load_x(xo);
@@ -452,21 +464,38 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                         int xo[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_full[mt] + (dy * IW + dx) * 32;
-                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, false, next_chunk, xo);
-                        else                              k_step(std::false_type{}, tap == 0, MORE && tap == 0, next_chunk, xo);
+                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, std::integral_constant<int, D - 1>{}, false, false, next_chunk, xo);
+                        else                              k_step(std::false_type{}, std::integral_constant<int, D - 1>{}, tap == 0, MORE && tap == 0, next_chunk, xo);
                     }
                 } else {
-#pragma unroll
-                    for (int hs = 0; hs < HSTEPS; ++hs) {
+                    static_for<HSTEPS>([&](auto hs_c) {
+                        constexpr int hs = decltype(hs_c)::value;
                         const int t0 = 2 * hs, t1 = (2 * hs + 1 < TAPS) ? 2 * hs + 1 : 0;   // padded half has zero weights
                         const int o0 = ((t0 / KS) * IW + (t0 % KS)) * 32, o1 = ((t1 / KS) * IW + (t1 % KS)) * 32;
                         const int to = (kq >> 1) ? o1 : o0;
                         int xo[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
-                        if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, false, next_chunk, xo);
-                        else                            k_step(std::false_type{}, hs == 0, MORE && hs == 0, next_chunk, xo);
-                    }
+                        if constexpr (EARLY_T) {
+                            // the next raw chunk is issued in step 0 (behind that step's weight refill): it may still be
+                            // in flight at step 1's wait and has landed at the waits of steps >= 2, which leave only the
+                            // hs-1 refills issued after it outstanding; its slots are transformed under steps 2..
+                            constexpr int WG = (hs >= 2 && hs - 1 < D - 1) ? hs - 1 : D - 1;
+                            if (MORE && hs == 1)                 k_step(std::true_type{}, std::integral_constant<int, D - 1>{}, false, false, next_chunk, xo);
+                            else if (MORE && hs >= 2)            k_step(std::false_type{}, std::integral_constant<int, WG>{}, false, false, next_chunk, xo);
+                            else                                 k_step(std::false_type{}, std::integral_constant<int, D - 1>{}, hs == 0, MORE && hs == 0, next_chunk, xo);
+                            if constexpr (hs >= 2) {
+                                if (MORE) {
+                                    constexpr int SPS = (APW + (HSTEPS - 2) - 1) / (HSTEPS - 2);      // slots per step
+#pragma unroll
+                                    for (int sl = (hs - 2) * SPS; sl < (hs - 1) * SPS && sl < APW; ++sl) transform_slot(next_chunk, sl);
+                                }
+                            }
+                        } else {
+                            if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, std::integral_constant<int, D - 1>{}, false, false, next_chunk, xo);
+                            else                            k_step(std::false_type{}, std::integral_constant<int, D - 1>{}, hs == 0, MORE && hs == 0, next_chunk, xo);
+                        }
+                    });
                 }
             };
             if (more) {
@@ -478,6 +507,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
                 else wait_vm_and_barrier<0>();
                 TS(TS_CHUNK_WAIT)
+                if constexpr (EARLY_T) commit(next_chunk);      // computed under the last steps' MFMAs; frees its registers before the epilogue
                 if (!more_in_tile) {                    // tile finished: store it, move to the next one
                     epilogue();
                     trem = next_tile;
@@ -487,7 +517,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     ts_after_epi = true;
 #endif
                 }
-                transform(next_chunk);
+                if constexpr (!EARLY_T) transform(next_chunk);
                 TS(TS_TRANSFORM)
                 if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -577,8 +607,7 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
 
 // ~3 resident workgroups per CU; a sample's tiles are dealt evenly to its persistent workgroups
 int conv16_wgs_per_img(int tiles, int B, int ny, int target) {
-    static const int target_env = getenv("MIDD_PERSIST_WGS") ? atoi(getenv("MIDD_PERSIST_WGS")) : 0;
-    const int target_wgs = target_env ? target_env : (target ? target : 768);
+    const int target_wgs = target ? target : 768;
     int per_img = target_wgs / (B * ny);
     if (per_img < 1) per_img = 1;
     if (per_img > tiles) per_img = tiles;
@@ -586,15 +615,18 @@ int conv16_wgs_per_img(int tiles, int B, int ny, int target) {
     return (tiles + tiles_per_wg - 1) / tiles_per_wg;
 }
 
+// Tiles the picker can reach.  Measured and dropped (same-box A/B at B=8, 256x256, round 1 and again in round 2 on the
+// atomics-statistics build): 16x16-pixel tiles (MT = 4: -2..-3 %), 96-cout tiles (NT = 6: -1.7 %), 4x2-wave and 8-wave
+// workgroups (neutral to negative).
 #define MIDD_CONV16_TILES(X)                  \
     /*  tw  mt nt wm wn */                    \
-    X(16, 4, 3, 4, 1) X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) X(16, 1, 3, 8, 1) X(16, 2, 6, 4, 1) \
-    X(16, 2, 3, 4, 2) X(16, 4, 3, 2, 2) X(16, 2, 3, 2, 2) X(16, 1, 3, 2, 2) X(8, 1, 3, 1, 2) \
-    X(16, 4, 3, 1, 3) X(16, 2, 3, 1, 3) X(8, 1, 3, 1, 3)                   \
-    X(16, 4, 3, 1, 4) X(16, 2, 3, 1, 4) X(8, 2, 3, 1, 4) X(8, 1, 3, 1, 4)  \
-    X(16, 4, 2, 4, 1) X(16, 2, 2, 4, 1) X(8, 1, 2, 2, 1)                   \
-    X(16, 4, 2, 2, 2) X(16, 2, 2, 2, 2) X(8, 1, 2, 1, 2)                   \
-    X(16, 4, 1, 4, 1) X(16, 2, 1, 4, 1) X(8, 1, 1, 2, 1)
+    X(16, 2, 3, 4, 1) X(16, 1, 3, 4, 1) X(8, 1, 3, 2, 1) \
+    X(16, 2, 3, 2, 2) X(16, 1, 3, 2, 2) X(8, 1, 3, 1, 2) \
+    X(16, 2, 3, 1, 3) X(8, 1, 3, 1, 3)                   \
+    X(16, 2, 3, 1, 4) X(8, 2, 3, 1, 4) X(8, 1, 3, 1, 4)  \
+    X(16, 2, 2, 4, 1) X(8, 1, 2, 2, 1)                   \
+    X(16, 2, 2, 2, 2) X(8, 1, 2, 1, 2)                   \
+    X(16, 2, 1, 4, 1) X(8, 1, 1, 2, 1)
 
 struct Tile16 { int tw, mt, nt, wm, wn; };
 static const Tile16 kTiles16[] = {
@@ -612,7 +644,7 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
     const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4 + 64;
-    long ring = (((d.nt > 3 || d.mt > 2) ? 80 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
+    long ring = ((long)MIDD_LDS_TARGET_KB * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
@@ -623,45 +655,24 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
     if (ks == 1 && conv1x1_pick_tile(Cin, Cout, B, OH, OW, t)) return true;      // dedicated 1x1 kernel (conv1x1_f16x3.hip)
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
-    const int nn = Cout / (16 * nt);                      // cout slices of 16*nt; a workgroup takes wn of them
     const Tile16* best = nullptr;
     long best_score = -(1L << 60);
-    // 16x16-pixel tiles (MT = 4, two workgroups per CU) halve the weight bytes streamed per MAC.  Measured (B=8,
-    // 256x256 input): -5..-12 % on the 3x3 convs whose tensors stay in the Infinity Cache and whose weight stream
-    // dominates (128x128 maps, >= 96 input channels); +15..35 % on the HBM-bound 256x256 maps (they need the third
-    // workgroup's loads in flight) and on maps too small to give every CU two such workgroups.
-    static const int max_mt_env = getenv("MIDD_MAX_MT") ? atoi(getenv("MIDD_MAX_MT")) : 0;
-    const double moved_mb = 4.0 * B * ((double)OH * stride * OW * stride * Cin + (double)OH * OW * Cout) / 1048576.0;
-    const long wgs_mt4 = (long)B * ((OW + 15) / 16) * ((OH + 15) / 16) * (Cout / (16 * ((Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1)));
-    // With the batch split over two streams (the default) the selective rule is a net loss (-1.5..-3 %; +0.4 %
-    // unsplit), so it is opt-in.
-    static const int big_rule = getenv("MIDD_TILE_BIG") ? atoi(getenv("MIDD_TILE_BIG")) : 0;
-    const bool big_ok = big_rule && ks == 3 && stride == 1 && Cin >= 96 && moved_mb <= 96.0 && wgs_mt4 >= 512;
-    const int max_mt = max_mt_env ? max_mt_env : (big_ok ? 4 : 2);
-    // 192, not 256: at B=4 (half-batches) the 32x32 layers with 144 couts would otherwise drop to 32-pixel 2-wave
-    // tiles that stream the weights twice as often (same-box A/B: +1.7 %)
-    static const long min_wgs = getenv("MIDD_MIN_WGS") ? atol(getenv("MIDD_MIN_WGS")) : 192;
-    static const int pix_first = getenv("MIDD_PIX_FIRST") ? atoi(getenv("MIDD_PIX_FIRST")) : 1;
-    static const int wide_ok = getenv("MIDD_TILE_NT6") ? atoi(getenv("MIDD_TILE_NT6")) : 0;
+    // 192, not 256 workgroups: at B=4 (half-batches) the 32x32 layers with 144 couts would otherwise drop to 32-pixel
+    // 2-wave tiles that stream the weights twice as often (same-box A/B: +1.7 %)
+    constexpr long min_wgs = 192;
     for (const Tile16& d : kTiles16) {
-        const bool wide = (d.nt == 2 * nt) && wide_ok && (Cout % (16 * d.nt) == 0);
-        if (d.nt != nt && !wide) continue;
-        const int nn_d = Cout / (16 * d.nt);
+        if (d.nt != nt) continue;
+        const int nn_d = Cout / (16 * d.nt);              // cout slices of 16*nt; a workgroup takes wn of them
         if (nn_d % d.wn) continue;
-        if (d.mt > max_mt) continue;
         if (!tile16_fits(d, ks, stride)) continue;
         const int bm = d.wm * d.mt * 16, th = bm / d.tw;
         const long tiles = (long)((OW + d.tw - 1) / d.tw) * ((OH + th - 1) / th);
         const long wgs = (long)B * tiles * (nn_d / d.wn);
         const long covered = tiles * d.tw * th;
         const bool wasteful = covered * 4 > (long)OH * OW * 5;
-        // enough workgroups first; then the pixels one weight fetch is shared over (the weight stream
-        // from L2 is what starves small tiles), then the couts one activation staging is shared over
-        static const long w8_below = getenv("MIDD_W8_BELOW") ? atol(getenv("MIDD_W8_BELOW")) : 0;
-        if (d.wm == 8 && wgs >= w8_below) continue;          // 8-wave tiles only where one workgroup per CU is all there is
-        static const int allow_4x2 = getenv("MIDD_TILE_4X2") ? atoi(getenv("MIDD_TILE_4X2")) : 0;
-        if (d.wm == 4 && d.wn == 2 && !allow_4x2) continue;
-        const long share = (pix_first ? (long)bm * 8 + d.wn : (long)d.wn * 1024 + bm) + (d.wm == 8 ? 4 : 0) + (wide ? 2 : 0);
+        // enough workgroups first; then the pixels one weight fetch is shared over (the weight stream from L2 is what
+        // starves small tiles), then the couts one activation staging is shared over
+        const long share = (long)bm * 8 + d.wn;
         const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }
     }
@@ -672,7 +683,6 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
 
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
-    if (a.prologue == PRO_PRE_DMA) return conv3x3_pre_launch(a, t, s);
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
         if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \

@@ -21,7 +21,6 @@
 using namespace midd;
 
 static const int ATTN_HEADS_ABI = 2;     // AttentionBlock(num_heads=2), DDIMModel.py:136
-static const int MAX_SCHED = 4096;       // iterations one mi_denoise call may replay from the device schedule
 
 // ------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -64,17 +63,15 @@ struct TensorRef {
 
 struct GnRef { size_t gamma = 0, beta = 0; bool on = false; };        // affine of the GroupNorm in front of a consumer
 
-enum OpKind { OP_IN_CONV, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_TOT, OP_PREACT };
+enum OpKind { OP_IN_CONV, OP_CONV, OP_ATTN, OP_RESIZE, OP_CONVT, OP_OUT, OP_CHAN_TOT };
 struct Op {
     OpKind kind;
     // sources / destination (workspace offsets in bytes)
     TensorRef s0, s1, dst, resid;
     bool has_s1 = false, has_resid = false;
-    GnRef gn;                   // OP_CONV / OP_PREACT / OP_OUT: GroupNorm of (s0, s1) applied while staging
+    GnRef gn;                   // OP_CONV / OP_OUT: GroupNorm of (s0, s1) applied while staging
     size_t partial_off = 0;     // OP_ATTN: pre-split K / V^T scratch
     int stat_rows = 0;          // OP_CHAN_TOT: blocks per sample
-    bool on_side = false;       // runs on the part's branch stream, next to the ops that follow it (res_conv next to conv1)
-    bool joins_side = false;    // first op that needs the branch's result
     // OP_CONV
     size_t w = 0, b = 0;
     int prologue = PRO_RAW, temb_col = -1;
@@ -88,7 +85,7 @@ struct Program {
     int B, H, W;
     int persist_wgs = 0;       // f16x3 convs: persistent-workgroup target of this program (0 = default)
     std::vector<Op> ops;
-    size_t bytes = 0, trow_off = 0, sched_off = 0, counter_off = 0;
+    size_t bytes = 0, trow_off = 0;
     size_t stats_off = 0, stats_bytes = 0;      // statistics arena: every tensor's totals, zeroed by one memset per forward
     std::map<std::string, TensorRef> outputs;
 };
@@ -103,26 +100,17 @@ struct mi_plan {
     // device side
     float* wdev = nullptr; size_t wdev_floats = 0;
     float* ttab = nullptr; int time_rows = 0;
-    size_t w_in = 0, b_in = 0, g_out = 0, be_out = 0, w_out = 0, b_out = 0, zeros_off = 0;
+    size_t w_in = 0, b_in = 0, g_out = 0, be_out = 0, w_out = 0, b_out = 0;
     bool finalized = false;
     int device = -1;
     std::mutex mu;
     std::map<uint64_t, std::unique_ptr<Program>> programs;
-    // captured sampler iteration (one hipGraph per program + pointer set), replayed n_iters times
-    struct GraphEntry { uint64_t key[6]; hipGraphExec_t exec; };
-    std::vector<GraphEntry> graphs;
-    hipStream_t gstream = nullptr;
-    hipEvent_t gev_in = nullptr, gev_out = nullptr;
     // two half-batches on two streams (mi_denoise): side stream + fork / phase / join events
     static const int MAX_PARTS = 4;
     hipStream_t sstream[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};        // [0] unused (caller's stream)
     hipEvent_t sev_fork = nullptr, sev_phase[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr},
                sev_join[MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex side_mu;
-    // per part: a branch stream for ops that only depend on the block input (ResidualBlock.res_conv runs beside conv1:
-    // DDIMModel.py:126,133) + fork / join events
-    struct Branch { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-    Branch branch[MAX_PARTS];
     // profiling (mi_profile_begin/end)
     bool profiling = false;
     struct Span { hipEvent_t a, b; std::string name; double flops, bytes; };
@@ -490,7 +478,6 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
         if (!getw(plan, k)) return fail(MI_ESTATE, "missing key in state_dict: \"%s\"", k.c_str());
 
     Packer pk;
-    { std::vector<float> z(64, 0.f); plan->zeros_off = pk.put(z); }
     const bool f16 = plan->cfg.compute_mode == MI_COMPUTE_F16X3;
     auto pack_conv = [&](const float* w, int Cout, int Cin, int KS, float* scale) {
         *scale = 1.0f;
@@ -554,12 +541,10 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
     std::vector<float> table = build_time_table(plan, time_rows);
 
     HIPCHK(hipGetDevice(&plan->device));
-    // Programs cache per-layer values derived from the weights (Op::out_scale = 2^-k of the f16x3 packing) and
-    // captured graphs hold wdev/ttab pointers: both are rebuilt after every (re)finalize.  hipFree below
-    // synchronises the device, so nothing that still reads the old buffers is in flight.
+    // Programs cache per-layer values derived from the weights (Op::out_scale = 2^-k of the f16x3 packing): they are
+    // rebuilt after every (re)finalize.  hipFree below synchronises the device, so nothing that still reads the old
+    // buffers is in flight.
     plan->programs.clear();
-    for (auto& ge : plan->graphs) (void)hipGraphExecDestroy(ge.exec);
-    plan->graphs.clear();
     if (plan->wdev) { HIPCHK(hipFree(plan->wdev)); plan->wdev = nullptr; }
     if (plan->ttab) { HIPCHK(hipFree(plan->ttab)); plan->ttab = nullptr; }
     HIPCHK(hipMalloc((void**)&plan->wdev, pk.buf.size() * sizeof(float)));
@@ -610,19 +595,6 @@ struct Builder {
                             ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
                             : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
-        // Opt-in: pre-activated, DMA-only activation staging (conv3x3_pre_f16x3.hip) for 3x3 stride-1 convs behind a
-        // GroupNorm on maps of at most MIDD_PREDMA_MAX_HW pixels (0 = never), where the picked tile has that kernel.
-        static const long predma_max_hw = getenv("MIDD_PREDMA_MAX_HW") ? atol(getenv("MIDD_PREDMA_MAX_HW")) : 0;
-        if (gn.on && ks == 3 && stride == 1 && p->cfg.compute_mode == MI_COMPUTE_F16X3 &&
-            (long)s0.H * s0.W <= predma_max_hw && conv3x3_pre_supports(o.tile) && dst.C % 48 == 0) {
-            Op pre{}; pre.kind = OP_PREACT; pre.s0 = s0; if (s1) { pre.s1 = *s1; pre.has_s1 = true; }
-            pre.gn = gn; pre.prologue = prologue;
-            TensorRef t; t.C = s0.C + (s1 ? s1->C : 0); t.H = s0.H; t.W = s0.W;
-            t.off = bump.take((size_t)B * t.H * t.W * t.C * sizeof(float));
-            pre.dst = t;
-            g->ops.push_back(pre);
-            o.s0 = t; o.has_s1 = false; o.prologue = PRO_PRE_DMA; o.gn = GnRef{};
-        }
         if (want_stats) { alloc_stats(dst); o.want_stats = true; }
         o.dst = dst;
         g->ops.push_back(o);
@@ -638,8 +610,6 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     g->B = B; g->H = H; g->W = W;
     Builder bld{p, g, Bump{}, B};
     g->trow_off = bld.bump.take((size_t)B * sizeof(int));
-    g->counter_off = bld.bump.take(256);
-    g->sched_off = bld.bump.take((size_t)MAX_SCHED * sizeof(StepSched));
     int rc;
 
     const GnRef no_gn{};
@@ -648,19 +618,16 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         if (cin != m.in_c) return fail(MI_EINVAL, "%s: expected %d input channels, graph provides %d", m.name.c_str(), m.in_c, cin);
         TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
         TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
-        // res_conv(x) needs nothing but the block input: it is issued first, on the part's branch stream, and runs
-        // beside conv1; conv2 (which adds it in place) is the join
-        static const bool branch_on = !(getenv("MIDD_BRANCH") && atoi(getenv("MIDD_BRANCH")) == 0);
+        // res_conv(x) first: it needs nothing but the block input.  (Running it beside conv1 on a third stream was
+        // measured: -2 % at B = 8, -4 % at B = 1 -- event traffic and a third kernel competing for the CUs.)
         if (m.in_c != m.out_c) {
             if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, no_gn, -1, nullptr, false))) return rc;   // res_conv(x)
-            g->ops.back().on_side = branch_on;
         }
         if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
         const GnRef g2{m.g2, m.be2, true};
         if (m.in_c != m.out_c) {
             const TensorRef acc = o;
             if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &acc, true))) return rc;   // + in place
-            g->ops.back().joins_side = branch_on;
         } else {
             if (s1) return fail(MI_EINVAL, "%s: identity residual over a concatenated input", m.name.c_str());
             if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &s0, true))) return rc;
@@ -765,8 +732,7 @@ static int get_program(mi_plan* p, int B, int H, int W, Program** out, bool side
     auto it = p->programs.find(key);
     if (it == p->programs.end()) {
         std::unique_ptr<Program> g(new Program());
-        static const int side_wgs = getenv("MIDD_PERSIST_WGS_SPLIT") ? atoi(getenv("MIDD_PERSIST_WGS_SPLIT")) : 640;
-        g->persist_wgs = side_by_side ? side_wgs : 0;
+        g->persist_wgs = side_by_side ? 640 : 0;
         int rc = build_program(p, B, H, W, g.get());
         if (rc) return rc;
         it = p->programs.emplace(key, std::move(g)).first;
@@ -800,7 +766,6 @@ extern "C" size_t mi_workspace_bytes(mi_plan* plan, int B, int H, int W) {
 struct StepIO {
     const float* x; const float* cond; float* eps_out;
     float* x_update; const float* noise; float c1, c2, c3; int clamp_eps;
-    bool from_sched = false; size_t noise_stride = 0;     // graph-replay form: per-iteration values live on the device
 };
 
 // Kernel symbol + algorithmic work of one op (for mi_profile_*).
@@ -815,12 +780,9 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             *bytes = 4.0 * (2.0 * B * p->cfg.in_channels * g->H * g->W + elems(o.dst));
             break;
         case OP_CHAN_TOT: *name = "midd::chan_total_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
-        case OP_PREACT: *name = "midd::preact_kernel"; *flops = 0; *bytes = 8.0 * elems(o.dst); break;
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
                 snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d>", o.tile.mt, o.tile.nt);
-            else if (o.prologue == PRO_PRE_DMA)
-                snprintf(buf, sizeof(buf), "midd::conv3x3_pre_f16x3_kernel<%d>", o.tile.mt);
             else
                 snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
                          p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
@@ -853,44 +815,17 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
     }
 }
 
-static int ensure_branch(mi_plan* p, int part) {
-    mi_plan::Branch& br = p->branch[part];
-    if (br.stream) return MI_OK;
-    HIPCHK(hipStreamCreateWithFlags(&br.stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&br.fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&br.join, hipEventDisableTiming));
-    return MI_OK;
-}
-
-// Callers hold plan->side_mu: the branch streams / events are per plan.
-static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s_main, int part = 0,
+static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s,
                        hipEvent_t mid_event = nullptr, int mid_div = 2) {
-    if (int rcb = ensure_branch(p, part)) return rcb;
-    const mi_plan::Branch& br = p->branch[part];
-    bool side_pending = false;              // a branch kernel has been issued and not yet joined
-    struct JoinGuard {                      // whatever happens below, the caller's stream ends up behind the branch
-        const mi_plan::Branch& br; hipStream_t s; bool& pending;
-        ~JoinGuard() { if (pending && (hipEventRecord(br.join, br.stream) != hipSuccess || hipStreamWaitEvent(s, br.join, 0) != hipSuccess)) (void)hipStreamSynchronize(br.stream); }
-    } guard{br, s_main, side_pending};
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
     const int B = g->B;
     auto T = [&](size_t off) { return reinterpret_cast<stat_word*>(ws + off); };
     // every tensor's GroupNorm totals start the forward at zero (producers accumulate with atomics)
-    if (hipMemsetAsync(ws + g->stats_off, 0, g->stats_bytes, s_main) != hipSuccess) return fail(MI_EHIP, "clearing the statistics arena failed");
+    if (hipMemsetAsync(ws + g->stats_off, 0, g->stats_bytes, s) != hipSuccess) return fail(MI_EHIP, "clearing the statistics arena failed");
     for (const Op& o : g->ops) {
         hipError_t e = hipSuccess;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
-        hipStream_t s = s_main;
-        if (o.on_side) {                    // fork: the branch starts where the main stream is now
-            if (hipEventRecord(br.fork, s_main) != hipSuccess || hipStreamWaitEvent(br.stream, br.fork, 0) != hipSuccess)
-                return fail(MI_EHIP, "branch fork failed");
-            s = br.stream;
-        } else if (o.joins_side && side_pending) {
-            if (hipEventRecord(br.join, br.stream) != hipSuccess || hipStreamWaitEvent(s_main, br.join, 0) != hipSuccess)
-                return fail(MI_EHIP, "branch join failed");
-            side_pending = false;
-        }
         if (p->profiling) {
             auto take = [&]() -> hipEvent_t {
                 hipEvent_t ev = nullptr;
@@ -907,16 +842,6 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), B, p->cfg.in_channels,
                                    g->H, g->W, o.dst.C, s);
                 break;
-            case OP_PREACT: {
-                PreactArgs a{};
-                a.src0 = F(o.s0.off); a.C0 = o.s0.C; a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
-                a.gn_tot0 = T(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : nullptr;
-                a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
-                a.silu = o.prologue == PRO_GN_SILU ? 1 : 0; a.out = reinterpret_cast<unsigned*>(ws + o.dst.off);
-                a.B = B; a.HW = o.s0.H * o.s0.W;
-                e = preact_launch(a, s);
-                break;
-            }
             case OP_CHAN_TOT:
                 e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
                 break;
@@ -933,7 +858,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
-                a.out = F(o.dst.off); a.out_scale = o.out_scale; a.zeros = wd + p->zeros_off;
+                a.out = F(o.dst.off); a.out_scale = o.out_scale;
                 if (o.want_stats) a.stat_tot = T(o.dst.tot_off);
                 a.persist_wgs = g->persist_wgs;
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
@@ -957,20 +882,13 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
                 a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;
                 a.c1 = io.c1; a.c2 = io.c2; a.c3 = io.c3; a.clamp_eps = io.clamp_eps;
-                if (io.from_sched) {
-                    a.sched = reinterpret_cast<const StepSched*>(ws + g->sched_off);
-                    a.step_counter = reinterpret_cast<const int*>(ws + g->counter_off);
-                    a.noise_stride = io.noise_stride;
-                }
                 e = out_conv_launch(a, s);
                 break;
             }
         }
         if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
-        if (o.on_side) side_pending = true;
-        static const int phase_pct = getenv("MIDD_PHASE_PCT") ? atoi(getenv("MIDD_PHASE_PCT")) : 0;
-        const size_t mid_at = phase_pct ? g->ops.size() * phase_pct / 100 : g->ops.size() / mid_div;
-        if (mid_event && (size_t)(&o - g->ops.data()) == mid_at) (void)hipEventRecord(mid_event, s_main);
+        const size_t mid_at = g->ops.size() / mid_div;
+        if (mid_event && (size_t)(&o - g->ops.data()) == mid_at) (void)hipEventRecord(mid_event, s);
         if (p->profiling) {
             (void)hipEventRecord(ev_b, s);
             mi_plan::Span sp; sp.a = ev_a; sp.b = ev_b;
@@ -1013,66 +931,7 @@ extern "C" int mi_unet_forward(mi_plan* plan, const float* x, const float* condi
     hipError_t e = fill_i32_launch(reinterpret_cast<int*>(ws + g->trow_off), t, B, s);
     if (e != hipSuccess) return fail(MI_EHIP, "fill timesteps: %s", hipGetErrorString(e));
     StepIO io{x, condition, eps, nullptr, nullptr, 0.f, 0.f, 0.f, 0};
-    std::lock_guard<std::mutex> lk(plan->side_mu);
     return run_program(plan, g, io, ws, s);
-}
-
-// The sampler loop as hipGraph replays: one forward + fused update is captured once per (program,
-// pointer set); the per-iteration values (timestep, coefficients, noise slice) come from a device
-// schedule indexed by a device counter, so the same executable graph serves every iteration.
-// Launches go to a plan-owned stream (the legacy null stream cannot be captured), ordered with the
-// caller's stream by events.
-static const int MI_EAGAIN_EAGER = 1;
-template <class CoefFn>
-static int denoise_graph(mi_plan* plan, Program* g, const float* noisy, float* x_out, int B,
-                         const int32_t* t_list, int n_iters, CoefFn coef, const float* step_noise, int flags,
-                         size_t img_elems, char* ws, hipStream_t user) {
-    std::lock_guard<std::mutex> lk(plan->mu);
-    if (!plan->gstream) {
-        if (hipStreamCreateWithFlags(&plan->gstream, hipStreamNonBlocking) != hipSuccess) return MI_EAGAIN_EAGER;
-        if (hipEventCreateWithFlags(&plan->gev_in, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&plan->gev_out, hipEventDisableTiming) != hipSuccess) return MI_EAGAIN_EAGER;
-    }
-    hipStream_t gs = plan->gstream;
-    const uint64_t key[6] = {(uint64_t)(uintptr_t)g, (uint64_t)(uintptr_t)ws, (uint64_t)(uintptr_t)noisy,
-                             (uint64_t)(uintptr_t)x_out, (uint64_t)(uintptr_t)step_noise, (uint64_t)flags};
-    hipGraphExec_t exec = nullptr;
-    for (auto& e : plan->graphs) if (!memcmp(e.key, key, sizeof(key))) { exec = e.exec; break; }
-    if (!exec) {
-        StepIO io{};
-        io.x = x_out; io.cond = noisy; io.x_update = x_out; io.noise = step_noise;
-        io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0; io.from_sched = true; io.noise_stride = img_elems;
-        if (hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal) != hipSuccess) return MI_EAGAIN_EAGER;
-        hipError_t e = step_begin_launch(reinterpret_cast<const StepSched*>(ws + g->sched_off),
-                                         reinterpret_cast<const int*>(ws + g->counter_off),
-                                         reinterpret_cast<int*>(ws + g->trow_off), B, gs);
-        int rc = (e == hipSuccess) ? run_program(plan, g, io, ws, gs) : MI_EHIP;
-        if (rc == MI_OK && step_end_launch(reinterpret_cast<int*>(ws + g->counter_off), gs) != hipSuccess) rc = MI_EHIP;
-        hipGraph_t graph = nullptr;
-        hipError_t ce = hipStreamEndCapture(gs, &graph);
-        if (rc != MI_OK || ce != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc ? rc : MI_EAGAIN_EAGER; }
-        hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) return MI_EAGAIN_EAGER;
-        if (plan->graphs.size() >= 8) { (void)hipGraphExecDestroy(plan->graphs.front().exec); plan->graphs.erase(plan->graphs.begin()); }
-        mi_plan::GraphEntry ge; memcpy(ge.key, key, sizeof(key)); ge.exec = exec;
-        plan->graphs.push_back(ge);
-    }
-    std::vector<StepSched> sched(n_iters);
-    for (int i = 0; i < n_iters; ++i) {
-        const int t = t_list[i];
-        coef(t, &sched[i].c1, &sched[i].c2, &sched[i].c3);
-        sched[i].t = t; sched[i].use_noise = (step_noise && t > 0) ? 1 : 0;                        // cddpmModels.py:297-300
-    }
-    HIPCHK(hipEventRecord(plan->gev_in, user));
-    HIPCHK(hipStreamWaitEvent(gs, plan->gev_in, 0));
-    HIPCHK(hipMemcpyAsync(ws + g->sched_off, sched.data(), sched.size() * sizeof(StepSched), hipMemcpyHostToDevice, gs));
-    HIPCHK(hipMemsetAsync(ws + g->counter_off, 0, sizeof(int), gs));
-    HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, gs));   // x = noisy_img.clone()
-    for (int i = 0; i < n_iters; ++i) HIPCHK(hipGraphLaunch(exec, gs));
-    HIPCHK(hipEventRecord(plan->gev_out, gs));
-    HIPCHK(hipStreamWaitEvent(user, plan->gev_out, 0));
-    return MI_OK;
 }
 
 extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, int W,
@@ -1092,20 +951,13 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const size_t img_elems = (size_t)B * plan->cfg.in_channels * H * W;
-    std::lock_guard<std::mutex> side_lk(plan->side_mu);      // the side / branch streams and their events are per plan: one enqueue at a time
+    std::lock_guard<std::mutex> side_lk(plan->side_mu);      // the side streams and their events are per plan: one enqueue at a time
     // fp32 arithmetic in the reference's order (DDIMModel.py:280-283)
     auto coef = [&](int t, float* c1, float* c2, float* c3) {
         *c1 = 1.0f / sqrtf(alpha[t]);
         *c2 = (1.0f - alpha[t]) / sqrtf(1.0f - alpha_hat[t]);
         *c3 = sqrtf(beta[t]);
     };
-    // hipGraph replay of the loop is available (MIDD_GRAPH=1) but off by default: measured on MI355X the
-    // eager stream is not launch-bound (B=8: 29.7 vs 29.1 img/s with replay; B=1: 6.4 vs 6.2)
-    static const bool use_graph = getenv("MIDD_GRAPH") && atoi(getenv("MIDD_GRAPH")) != 0;
-    if (use_graph && !plan->profiling && n_iters > 1 && n_iters <= MAX_SCHED) {
-        rc = denoise_graph(plan, g, noisy, x_out, B, t_list, n_iters, coef, step_noise, flags, img_elems, ws, s);
-        if (rc != MI_EAGAIN_EAGER) return rc;             // capture unavailable: fall through to eager launches
-    }
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, s));   // x = noisy_img.clone()
     const int parts = split_parts(B);
     if (parts > 1 && n_iters > 0) {
@@ -1143,7 +995,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
                     io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
                     if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
                     hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
-                    int rc2 = run_program(plan, gh, io, wsh, sh, h, mid, parts);
+                    int rc2 = run_program(plan, gh, io, wsh, sh, mid, parts);
                     if (rc2) return rc2;
                 }
             }
@@ -1229,15 +1081,6 @@ extern "C" void mi_plan_destroy(mi_plan* plan) {
     if (!plan) return;
     for (auto& sp : plan->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t ev : plan->event_pool) (void)hipEventDestroy(ev);
-    for (auto& ge : plan->graphs) (void)hipGraphExecDestroy(ge.exec);
-    if (plan->gev_in) (void)hipEventDestroy(plan->gev_in);
-    if (plan->gev_out) (void)hipEventDestroy(plan->gev_out);
-    if (plan->gstream) (void)hipStreamDestroy(plan->gstream);
-    for (auto& br : plan->branch) {
-        if (br.fork) (void)hipEventDestroy(br.fork);
-        if (br.join) (void)hipEventDestroy(br.join);
-        if (br.stream) (void)hipStreamDestroy(br.stream);
-    }
     if (plan->sev_fork) (void)hipEventDestroy(plan->sev_fork);
     for (int i = 0; i < mi_plan::MAX_PARTS; ++i) {
         if (plan->sev_phase[i]) (void)hipEventDestroy(plan->sev_phase[i]);

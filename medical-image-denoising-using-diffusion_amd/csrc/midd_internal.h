@@ -9,10 +9,7 @@
 namespace midd {
 
 // ---------------------------------------------------------------- implicit-GEMM convolution
-// PRO_PRE_DMA (f16x3, conv3x3_pre_f16x3.hip): the input is planar per 16-channel block -- 16 fp16 high halves then
-// 16 low halves per pixel of 2^s * act(GroupNorm(x)) (preact_kernel) -- i.e. already the MFMA image; staging is
-// LDS-DMA only.
-enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2, PRO_PRE_DMA = 4 };
+enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
 
 struct ConvArgs {
     const float* src0;      // NHWC, C0 channels
@@ -35,7 +32,6 @@ struct ConvArgs {
     const float* resid;     // NHWC [B][OH][OW][Cout] added in the epilogue, or null
     float* out;             // NHWC [B][OH][OW][Cout]
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
-    const float* zeros;     // (unused) 64 zero floats
     // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
     // the pixels it produced to the totals [B][Cout][2][3] (exact integer atomics, stats_common.h); zeroed per forward
     stat_word* stat_tot;
@@ -84,17 +80,6 @@ constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere 
 hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
-// GroupNorm-apply (+SiLU) + 2^s prescale + fp16 hi/lo split of a (virtually concatenated) NHWC tensor into the planar
-// operand image of PRO_PRE_DMA convolutions (groupnorm.hip)
-struct PreactArgs {
-    const float* src0; const float* src1; int C0, C1;
-    const stat_word* gn_tot0; const stat_word* gn_tot1; const float* gn_gamma; const float* gn_beta; float gn_eps;
-    int silu; unsigned* out; int B, HW;
-};
-hipError_t preact_launch(const PreactArgs& a, hipStream_t s);
-bool conv3x3_pre_supports(const ConvTile& t);
-hipError_t conv3x3_pre_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
-
 // ---------------------------------------------------------------- pre/post-processing (prepost.hip)
 size_t resize_workspace_bytes(int n, int sw, int sh, int dw, int dh);
 hipError_t resize_bicubic_u8_launch(const unsigned char* src, int n, int sw, int sh, unsigned char* dst, int dw, int dh, void* ws, hipStream_t s);
@@ -128,20 +113,8 @@ struct OutConvArgs {
     const float* noise;     // NCHW or null
     float c1, c2, c3;
     int clamp_eps;
-    // graph-replay form: when sched != null the coefficients and the noise slice of the current
-    // iteration are read from device memory (entry *step_counter), so one captured forward serves
-    // every iteration of the sampler loop
-    const struct StepSched* sched;
-    const int* step_counter;
-    size_t noise_stride;    // elements between consecutive iterations' noise tensors
 };
 hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s);
-
-// One iteration of the sampler loop as the device sees it (DDIMModel.py:275-283).
-struct StepSched { float c1, c2, c3; int t; int use_noise; int pad[3]; };
-// trow[b] = sched[*counter].t for all b  /  ++*counter   (first and last node of a captured forward)
-hipError_t step_begin_launch(const StepSched* sched, const int* counter, int* trow, int B, hipStream_t s);
-hipError_t step_end_launch(int* counter, hipStream_t s);
 
 // bilinear resize NHWC (align_corners=False), any size ratio
 hipError_t resize_bilinear_launch(const float* src, float* dst, int B, int H, int W, int C, int OH, int OW, hipStream_t s);

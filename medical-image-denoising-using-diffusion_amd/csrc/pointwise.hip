@@ -138,14 +138,8 @@ void out_conv_kernel(const OutConvArgs a) {
         float eps = acc[oc] + a.bias[oc];
         if (a.eps_out) a.eps_out[o] = eps;
         if (a.x) {
-            float c1 = a.c1, c2 = a.c2, c3 = a.c3;
+            const float c1 = a.c1, c2 = a.c2, c3 = a.c3;
             const float* noise = a.noise;
-            if (a.sched) {
-                const int it = *a.step_counter;
-                const StepSched sc = a.sched[it];
-                c1 = sc.c1; c2 = sc.c2; c3 = sc.c3;
-                noise = (a.noise && sc.use_noise) ? a.noise + (size_t)it * a.noise_stride : nullptr;
-            }
             // x <- clamp( (1/sqrt(alpha)) * (x - ((1-alpha)/sqrt(1-alpha_hat)) * eps) [+ sqrt(beta)*noise], 0, 1 )
             // evaluated with the reference's operation order and no fused multiply-add.
             if (a.clamp_eps) eps = fminf(fmaxf(eps, -5.0f), 5.0f);
@@ -257,21 +251,6 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
 hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, hipStream_t s) {
     const long total = (long)B * H * W * C;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, B, H, W, C);
-    return hipGetLastError();
-}
-
-__global__ void step_begin_kernel(const StepSched* sched, const int* counter, int* trow, int B) {
-    const int t = sched[*counter].t;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) trow[b] = t;
-}
-__global__ void step_end_kernel(int* counter) { *counter += 1; }
-
-hipError_t step_begin_launch(const StepSched* sched, const int* counter, int* trow, int B, hipStream_t s) {
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, s, sched, counter, trow, B);
-    return hipGetLastError();
-}
-hipError_t step_end_launch(int* counter, hipStream_t s) {
-    hipLaunchKernelGGL(step_end_kernel, dim3(1), dim3(1), 0, s, counter);
     return hipGetLastError();
 }
 

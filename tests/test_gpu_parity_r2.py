@@ -326,25 +326,17 @@ def test_statistics_are_never_stale_across_launches():
         assert torch.equal(model(a, a, torch.full((4,), 20, dtype=torch.long)), ea)
 
 
-def test_optional_kernels_are_reached():
-    """Child-process helper of test_gpu_optional_paths.py: with an opt-in knob in the environment, the kernel it
-    selects must actually be launched on the shapes that test runs (full network, B = 4, 64x64 and 256x256)."""
-    knobs = {k: os.environ.get(k) for k in ("MIDD_PREDMA_MAX_HW", "MIDD_TILE_BIG", "MIDD_TILE_NT6", "MIDD_CONV1X1_DIRECT")}
+def test_launched_kernels():
+    """What a forward launches, from the library's own per-kernel profile: the hand-written kernels and nothing else --
+    in particular no GroupNorm statistics / finalize kernel."""
     cfg = UNetConfig()
     model = _model({}, make_state_dict(cfg, seed=42))
-    names = set()
-    for size in (64, 256):
-        x = torch.from_numpy(synthetic_xray(4, size, size, seed=5)).cuda()
-        model.profile_begin()
-        model(x, x, torch.full((4,), 7, dtype=torch.long))
-        names |= {p["name"] for p in model.profile_end()}
-    print(sorted(names))
-    assert not any("gn_from_partial" in n for n in names), "GroupNorm finalize must not be a launch"
-    if knobs["MIDD_PREDMA_MAX_HW"]:
-        assert any("conv3x3_pre_f16x3_kernel" in n for n in names) and any("preact_kernel" in n for n in names)
-    if knobs["MIDD_TILE_BIG"]:
-        assert any("conv_mfma_f16x3_kernel<3, 1, 16, 4," in n for n in names)
-    if knobs["MIDD_TILE_NT6"]:
-        assert any("conv_mfma_f16x3_kernel<3, 1, 16, 2, 6," in n for n in names)
-    if knobs["MIDD_CONV1X1_DIRECT"] == "0":
-        assert not any("conv1x1_f16x3_kernel" in n for n in names) and any("conv_mfma_f16x3_kernel<1, 1," in n for n in names)
+    x = torch.from_numpy(synthetic_xray(4, 64, 64, seed=5)).cuda()
+    model.profile_begin()
+    model(x, x, torch.full((4,), 7, dtype=torch.long))
+    prof = model.profile_end()
+    names = {p["name"].split("<")[0] for p in prof}
+    print(sorted(names), sum(p["launches"] for p in prof), "launches")
+    assert names == {"midd::in_conv_kernel", "midd::chan_total_kernel", "midd::conv_mfma_f16x3_kernel", "midd::conv1x1_f16x3_kernel",
+                     "midd::attention_f16x3_kernel", "midd::resize_bilinear_kernel", "midd::out_conv_kernel"}
+    assert sum(p["launches"] for p in prof) == 92          # 143 in round 1 (51 GroupNorm finalize launches)
