@@ -1,7 +1,7 @@
-"""GPU: the two execution switches a user can set (environment, read once per process, so each runs in a child
+"""GPU: the execution switch a user can set (environment, read once per process, so each value runs in a child
 process) must keep parity:
-  MIDD_SPLIT=1    the batch as ONE program on the caller's stream (default: two half-batches on two streams)
-
+  MIDD_SPLIT=1 | 4   the batch as ONE program on the caller's stream / as four quarter-batches on four streams
+                     (default 2: two half-batches on two streams)"""
 import os
 import subprocess
 import sys
