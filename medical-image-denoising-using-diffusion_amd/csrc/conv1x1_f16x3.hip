@@ -218,7 +218,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
-            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + ntile_wg * 16 + c) * 2 + which) * STAT_LIMBS, t);
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ntile_wg * 16 + c, first_tile % STAT_REPLICAS, which), t);
         }
     }
 }

@@ -210,16 +210,14 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             dma16(base + byte_off, raw + (wave + s * NW) * 1024);
         }
     };
-    // The transform of a chunk = per slot: read the raw fp32 quad, GroupNorm-apply (+SiLU), 2^s prescale, hi/lo split
-    // (transform_slot: LDS read + VALU only, result in registers) and the write into the MFMA image (commit_slot).
-    // 3x3 kernels (EARLY_T) run the transform_slot part of chunk c+1 UNDER the MFMAs of chunk c's later steps -- the
-    // raw chunk lands during steps 0-1 -- and only the commits at the chunk boundary, where the whole transform used
-    // to sit (12-28 % of a workgroup's cycles, in-kernel stamps); 1x1 chunks are one or two steps long and keep it there.
-    constexpr bool EARLY_T = (KS == 3);
-    half4 t_hi[APW], t_lo[APW];
-    auto transform_slot = [&](int c, int s) {
+    // The transform of a chunk, per slot: read the raw fp32 quad, GroupNorm-apply (+SiLU), 2^s prescale, hi/lo split,
+    // write into the MFMA image.  (Measured in round 2: running the arithmetic of chunk c+1's transform under the MFMAs
+    // of chunk c's steps 2..4 and only the LDS writes at the chunk boundary is 2-4 % SLOWER end to end -- the waves
+    // reach the step barriers out of phase.)
+    auto transform = [&](int c) {
         const int blk = CB * c + sblk;
-        const int ch = (min(blk, nblk - 1) << 4) + (q8 & 3) * 4;
+        if (blk >= nblk) return;
+        const int ch = (blk << 4) + (q8 & 3) * 4;
         // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
         // raw operands (stride-2, folded ConvT, res_conv: not bounded by a GroupNorm) are split unscaled, so the
         // whole fp16 range (|x| < 65504) is available to them; normalised ones carry 2^s = 16
@@ -228,36 +226,31 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
             sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch) * ACT_PRESCALE;
         }
-        const int slot = tid + s * NTHREADS;
-        f32x4 v = *reinterpret_cast<const f32x4*>(raw + (g_off[s] > -2 ? slot : tid) * 16);
-        v = v * sc + sh;
-        if (a.prologue == PRO_GN_SILU) {
+        char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
-                v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+        for (int s = 0; s < APW; ++s) {
+            const int slot = tid + s * NTHREADS;
+            if (g_off[s] > -2) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(raw + slot * 16);
+                v = v * sc + sh;
+                if (a.prologue == PRO_GN_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
+                        v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+                }
+                if (g_off[s] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // the conv pads its (normalised) input with zeros
+                half4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)v[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)(v[e] - (float)h);
+                }
+                const int pix = slot / QPP;
+                *reinterpret_cast<half4*>(base + pix * 32) = hi;
+                *reinterpret_cast<half4*>(base + PLANE + pix * 32) = lo;
+            }
         }
-        if (g_off[s] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // the conv pads its (normalised) input with zeros
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const _Float16 h = (_Float16)v[e];
-            t_hi[s][e] = h;
-            t_lo[s][e] = (_Float16)(v[e] - (float)h);
-        }
-    };
-    auto commit_slot = [&](int c, int s) {
-        if (CB * c + sblk >= nblk || g_off[s] <= -2) return;
-        const int pix = (tid + s * NTHREADS) / QPP;
-        char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8 + pix * 32;
-        *reinterpret_cast<half4*>(base) = t_hi[s];
-        *reinterpret_cast<half4*>(base + PLANE) = t_lo[s];
-    };
-    auto transform = [&](int c) {
-#pragma unroll
-        for (int s = 0; s < APW; ++s) { transform_slot(c, s); commit_slot(c, s); }
-    };
-    auto commit = [&](int c) {
-#pragma unroll
-        for (int s = 0; s < APW; ++s) commit_slot(c, s);
     };
 
     // ---- per-lane LDS byte offsets of the B fragments (tap (0,0), block 0, hi plane) ----
@@ -353,11 +346,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // boundary), not on the step's barrier: they are requested first, so their LDS latency overlaps the wait.
     // `first` = first step of a chunk: its barrier is also the one that publishes the freshly transformed
     // image, so the fragments are read after it (WM == 1 has a dedicated barrier after the transform).
-    // `wgroups` = weight groups that may still be in flight at this step's wait (normally D-1; fewer once the next
-    // raw chunk, issued in step 0 behind that step's refill, has to have landed: EARLY_T, steps >= 2)
-    auto k_step = [&](auto with_a, auto wgroups, bool first, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
+    auto k_step = [&](auto with_a, bool first, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
         constexpr bool WITH_A = decltype(with_a)::value;
-        constexpr int N = decltype(wgroups)::value * PPW + (WITH_A ? APW : 0);
+        constexpr int N = (D - 1) * PPW + (WITH_A ? APW : 0);
         const bool early = (WM == 1) || !first;
         if (early) {
             load_x(xo);
@@ -439,7 +430,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
             const int ch = (ntile_wg + wn_i * NT) * 16 + c;
-            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + ch) * 2 + which) * STAT_LIMBS, t);
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ch, (blockIdx.x - b * a.wgs_per_img) % STAT_REPLICAS, which), t);
         }
     };
 
@@ -464,38 +455,21 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                         int xo[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_full[mt] + (dy * IW + dx) * 32;
-                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, std::integral_constant<int, D - 1>{}, false, false, next_chunk, xo);
-                        else                              k_step(std::false_type{}, std::integral_constant<int, D - 1>{}, tap == 0, MORE && tap == 0, next_chunk, xo);
+                        if (MORE && tap >= 1 && tap <= D) k_step(std::true_type{}, false, false, next_chunk, xo);
+                        else                              k_step(std::false_type{}, tap == 0, MORE && tap == 0, next_chunk, xo);
                     }
                 } else {
-                    static_for<HSTEPS>([&](auto hs_c) {
-                        constexpr int hs = decltype(hs_c)::value;
+#pragma unroll
+                    for (int hs = 0; hs < HSTEPS; ++hs) {
                         const int t0 = 2 * hs, t1 = (2 * hs + 1 < TAPS) ? 2 * hs + 1 : 0;   // padded half has zero weights
                         const int o0 = ((t0 / KS) * IW + (t0 % KS)) * 32, o1 = ((t1 / KS) * IW + (t1 % KS)) * 32;
                         const int to = (kq >> 1) ? o1 : o0;
                         int xo[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) xo[mt] = frag_base[mt] + to;
-                        if constexpr (EARLY_T) {
-                            // the next raw chunk is issued in step 0 (behind that step's weight refill): it may still be
-                            // in flight at step 1's wait and has landed at the waits of steps >= 2, which leave only the
-                            // hs-1 refills issued after it outstanding; its slots are transformed under steps 2..
-                            constexpr int WG = (hs >= 2 && hs - 1 < D - 1) ? hs - 1 : D - 1;
-                            if (MORE && hs == 1)                 k_step(std::true_type{}, std::integral_constant<int, D - 1>{}, false, false, next_chunk, xo);
-                            else if (MORE && hs >= 2)            k_step(std::false_type{}, std::integral_constant<int, WG>{}, false, false, next_chunk, xo);
-                            else                                 k_step(std::false_type{}, std::integral_constant<int, D - 1>{}, hs == 0, MORE && hs == 0, next_chunk, xo);
-                            if constexpr (hs >= 2) {
-                                if (MORE) {
-                                    constexpr int SPS = (APW + (HSTEPS - 2) - 1) / (HSTEPS - 2);      // slots per step
-#pragma unroll
-                                    for (int sl = (hs - 2) * SPS; sl < (hs - 1) * SPS && sl < APW; ++sl) transform_slot(next_chunk, sl);
-                                }
-                            }
-                        } else {
-                            if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, std::integral_constant<int, D - 1>{}, false, false, next_chunk, xo);
-                            else                            k_step(std::false_type{}, std::integral_constant<int, D - 1>{}, hs == 0, MORE && hs == 0, next_chunk, xo);
-                        }
-                    });
+                        if (MORE && hs >= 1 && hs <= D) k_step(std::true_type{}, false, false, next_chunk, xo);
+                        else                            k_step(std::false_type{}, hs == 0, MORE && hs == 0, next_chunk, xo);
+                    }
                 }
             };
             if (more) {
@@ -507,7 +481,6 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
                 else wait_vm_and_barrier<0>();
                 TS(TS_CHUNK_WAIT)
-                if constexpr (EARLY_T) commit(next_chunk);      // computed under the last steps' MFMAs; frees its registers before the epilogue
                 if (!more_in_tile) {                    // tile finished: store it, move to the next one
                     epilogue();
                     trem = next_tile;
@@ -517,7 +490,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     ts_after_epi = true;
 #endif
                 }
-                if constexpr (!EARLY_T) transform(next_chunk);
+                transform(next_chunk);
                 TS(TS_TRANSFORM)
                 if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -244,7 +244,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + r];
-            stat_atomic_add(a.stat_tot + (((size_t)b * a.Cout + c0 + wn_i * NT * 16 + c) * 2 + which) * STAT_LIMBS, t);
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, c0 + wn_i * NT * 16 + c, trem % STAT_REPLICAS, which), t);
         }
     }
 }

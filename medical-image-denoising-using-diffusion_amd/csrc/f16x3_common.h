@@ -1,8 +1,6 @@
 // Device helpers shared by the f16x3 convolution kernels (conv_mfma_f16x3.hip, conv1x1_f16x3.hip).
 #pragma once
 #include "midd_internal.h"
-#include <type_traits>
-#include <utility>
 
 namespace midd {
 
@@ -52,12 +50,6 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression in the body
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,

@@ -15,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int GN_THREADS = 256;
 
 // grid (rows, B): block `row` sums a contiguous pixel range of sample b per channel in fp64 (products of fp32 values
-// are exact in fp64), rounds the block's sums to fp32 and adds them to tot [B][C][2][3] with exact integer atomics.
+// are exact in fp64), rounds the block's sums to fp32 and adds them to tot [B][C][replica][2][3] with exact integer atomics.
 __global__ __launch_bounds__(GN_THREADS)
 void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int HW, int C, int rows) {
     extern __shared__ double red[];               // [ppi][C][2]
@@ -44,8 +44,8 @@ void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ to
     for (int c = tid; c < C; c += GN_THREADS) {
         double cs = 0, css = 0;
         for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
-        stat_word* o = tot + ((size_t)b * C + c) * STAT_WORDS;
-        stat_atomic_add(o, (float)cs); stat_atomic_add(o + STAT_LIMBS, (float)css);
+        stat_atomic_add(stat_slot(tot, b, C, c, row % STAT_REPLICAS, 0), (float)cs);
+        stat_atomic_add(stat_slot(tot, b, C, c, row % STAT_REPLICAS, 1), (float)css);
     }
 }
 

@@ -57,7 +57,7 @@ struct HostWeight { std::vector<int64_t> shape; std::vector<float> data; bool lo
 
 struct TensorRef {
     size_t off = 0; int C = 0, H = 0, W = 0;
-    // GroupNorm statistics, if produced: per-channel fixed-point totals [B][C][2][3] (stats_common.h), inside the statistics arena
+    // GroupNorm statistics, if produced: per-channel fixed-point totals [B][C][replica][2][3] (stats_common.h), inside the statistics arena
     size_t tot_off = (size_t)-1;
 };
 
@@ -574,7 +574,7 @@ struct Builder {
     size_t stats_cur = 0;
     void alloc_stats(TensorRef& t) {
         t.tot_off = stats_cur;
-        stats_cur += ((size_t)B * t.C * STAT_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
+        stats_cur += ((size_t)B * t.C * STAT_CH_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
     }
     // per-channel totals for a tensor no MFMA convolution produced
     void ensure_stats(TensorRef& t) {

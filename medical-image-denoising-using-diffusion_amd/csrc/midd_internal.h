@@ -21,7 +21,7 @@ struct ConvArgs {
     const float* bias;      // [Cout]
     int Cout;
     // GroupNorm of the INPUT (prologue != RAW): per-channel fixed-point (sum, sum of squares) totals of the two
-    // concatenated sources, [B][C0][2][3] / [B][C1][2][3] limbs, accumulated by the producers (stats_common.h); every
+    // concatenated sources, [B][C0][replica][2][3] / [B][C1][replica][2][3] limbs, accumulated by the producers (stats_common.h); every
     // workgroup derives scale = rstd*gamma, shift = beta - mean*rstd*gamma of its sample in its prologue
     const stat_word* gn_tot0; const stat_word* gn_tot1;
     const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_hw;      // affine [Cin], eps, pixels per channel
@@ -33,7 +33,7 @@ struct ConvArgs {
     float* out;             // NHWC [B][OH][OW][Cout]
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
-    // the pixels it produced to the totals [B][Cout][2][3] (exact integer atomics, stats_common.h); zeroed per forward
+    // the pixels it produced to the totals [B][Cout][replica][2][3] (exact integer atomics, stats_common.h); zeroed per forward
     stat_word* stat_tot;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
@@ -76,7 +76,7 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
 // ---------------------------------------------------------------- GroupNorm statistics (stats_common.h)
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
 // per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
-// sample each add their partial sums to tot [B][C][2][3]
+// sample each add their partial sums to tot [B][C][replica][2][3]
 hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
@@ -103,7 +103,7 @@ hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9
 
 struct OutConvArgs {
     const float* src;       // NHWC [B][H][W][C]
-    const stat_word* gn_tot; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][2][3], affine [C]
+    const stat_word* gn_tot; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][replica][2][3], affine [C]
     const float* w;         // [ic][9][C]
     const float* bias;      // [ic]
     int B, H, W, C, ic;

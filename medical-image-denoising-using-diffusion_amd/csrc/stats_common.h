@@ -21,8 +21,17 @@ namespace midd {
 
 constexpr int GN_GROUPS_C = 8;                    // nn.GroupNorm(8, C) everywhere in the reference
 constexpr int STAT_LIMBS = 3;                     // int64 limbs per total
-constexpr int STAT_WORDS = 2 * STAT_LIMBS;        // per channel: sum, sum of squares
+constexpr int STAT_WORDS = 2 * STAT_LIMBS;        // per replica: sum, sum of squares
+// Same-address atomics serialise at the memory side (~25 ns each, measured: a 640-workgroup launch at batch 1 spent
+// 13-25 us in them), so every channel keeps STAT_REPLICAS copies of its totals; a producer workgroup adds to copy
+// (its index mod STAT_REPLICAS), a consumer adds the copies' limbs (integers: exact, order-free) before converting.
+constexpr int STAT_REPLICAS = 8;
+constexpr int STAT_CH_WORDS = STAT_REPLICAS * STAT_WORDS;     // words per channel: layout [B][C][replica][sum | sumsq][limb]
 typedef unsigned long long stat_word;
+
+__device__ __forceinline__ stat_word* stat_slot(stat_word* tot, size_t b, int C, int c, int replica, int which) {
+    return tot + ((b * C + c) * STAT_REPLICAS + replica) * STAT_WORDS + which * STAT_LIMBS;
+}
 
 // totals[k] += limb k of v * 2^60 (exact for 2^-37 <= |v| < 2^59; smaller magnitudes are truncated towards zero at
 // 2^-60, far below fp32 resolution of any sum they could matter in)
@@ -55,8 +64,25 @@ __device__ __forceinline__ double stat_total(const stat_word* limbs) {
     return (double)l0 * 0x1p-60 + (double)l1 * 0x1p-20 + (double)l2 * 0x1p20;       // each limb is exact in fp64 (|l| < 2^53)
 }
 
+// one channel's (sum, sum of squares) from its STAT_REPLICAS copies: 16-byte loads, integer limb sums, one conversion
+__device__ __forceinline__ void stat_channel(const stat_word* __restrict__ p, double& s1, double& s2) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    stat_word acc[STAT_WORDS];
+#pragma unroll
+    for (int i = 0; i < STAT_WORDS; ++i) acc[i] = 0;
+#pragma unroll
+    for (int r = 0; r < STAT_REPLICAS; ++r) {
+#pragma unroll
+        for (int i = 0; i < STAT_WORDS; i += 2) {
+            const u64x2 v = *reinterpret_cast<const u64x2*>(p + r * STAT_WORDS + i);
+            acc[i] += v[0]; acc[i + 1] += v[1];
+        }
+    }
+    s1 = stat_total(acc); s2 = stat_total(acc + STAT_LIMBS);
+}
+
 // GroupNorm scale/shift of sample b into LDS: gnp[c] = mult * rstd * gamma[c], gnp[Cin + c] = mult * (beta[c] - mean * rstd * gamma[c]).
-// tot0 / tot1: totals [B][C0][2][3] / [B][C1][2][3] of the two concatenated sources (tot1 is not read when C1 == 0);
+// tot0 / tot1: totals [B][C0][replica][2][3] / [B][C1][...] of the two concatenated sources (tot1 is not read when C1 == 0);
 // hw = pixels per channel.  Wave w handles groups w, w + nwaves, ...: lane l takes channel g*cg + l (+64, ...), a
 // 64-lane butterfly (commutative adds: every lane ends with the same bits) gives the group sums, mean / rstd in fp64.
 // Visible to the workgroup after its next barrier.  Called by all threads.
@@ -71,23 +97,12 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
         const int g0 = wave, g1 = wave + nwaves;
         const bool on0 = g0 < GN_GROUPS_C && lane < cg, on1 = g1 < GN_GROUPS_C && lane < cg;
         const int c0 = g0 * cg + lane, c1 = g1 * cg + lane;
-        stat_word w0[STAT_WORDS], w1[STAT_WORDS];
         float ga0 = 0.f, be0 = 0.f, ga1 = 0.f, be1 = 0.f;
-#pragma unroll
-        for (int i = 0; i < STAT_WORDS; ++i) { w0[i] = 0; w1[i] = 0; }
-        if (on0) {
-            const stat_word* p = (c0 < C0) ? tot0 + ((size_t)b * C0 + c0) * STAT_WORDS : tot1 + ((size_t)b * C1 + (c0 - C0)) * STAT_WORDS;
-#pragma unroll
-            for (int i = 0; i < STAT_WORDS; ++i) w0[i] = p[i];
-            ga0 = gamma[c0]; be0 = beta[c0];
-        }
-        if (on1) {
-            const stat_word* p = (c1 < C0) ? tot0 + ((size_t)b * C0 + c1) * STAT_WORDS : tot1 + ((size_t)b * C1 + (c1 - C0)) * STAT_WORDS;
-#pragma unroll
-            for (int i = 0; i < STAT_WORDS; ++i) w1[i] = p[i];
-            ga1 = gamma[c1]; be1 = beta[c1];
-        }
-        double s1a = stat_total(w0), s2a = stat_total(w0 + STAT_LIMBS), s1b = stat_total(w1), s2b = stat_total(w1 + STAT_LIMBS);
+        double s1a = 0, s2a = 0, s1b = 0, s2b = 0;
+        if (on0) { ga0 = gamma[c0]; be0 = beta[c0]; }
+        if (on1) { ga1 = gamma[c1]; be1 = beta[c1]; }
+        if (on0) stat_channel((c0 < C0) ? tot0 + ((size_t)b * C0 + c0) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c0 - C0)) * STAT_CH_WORDS, s1a, s2a);
+        if (on1) stat_channel((c1 < C0) ? tot0 + ((size_t)b * C0 + c1) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c1 - C0)) * STAT_CH_WORDS, s1b, s2b);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             s1a += __shfl_xor(s1a, off, 64); s2a += __shfl_xor(s2a, off, 64);
@@ -114,8 +129,9 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
         double s1 = 0, s2 = 0;
         for (int l = lane; l < cg; l += 64) {
             const int c = g * cg + l;
-            const stat_word* p = (c < C0) ? tot0 + ((size_t)b * C0 + c) * STAT_WORDS : tot1 + ((size_t)b * C1 + (c - C0)) * STAT_WORDS;
-            s1 += stat_total(p); s2 += stat_total(p + STAT_LIMBS);
+            double c1v, c2v;
+            stat_channel((c < C0) ? tot0 + ((size_t)b * C0 + c) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c - C0)) * STAT_CH_WORDS, c1v, c2v);
+            s1 += c1v; s2 += c2v;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
