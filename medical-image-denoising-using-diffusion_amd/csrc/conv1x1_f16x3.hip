@@ -90,7 +90,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         }
     }
     if (a.prologue != PRO_RAW)            // GroupNorm scale / shift of this sample, the 2^s prescale folded in (exact)
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
     for (int i = tid; i < G::STAT_FLOATS; i += G::NTHREADS) stat_lds[i] = 0.f;
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
@@ -218,7 +218,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
-            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ntile_wg * 16 + c, first_tile % STAT_REPLICAS, which), t);
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ntile_wg * 16 + c, a.stat_rep, first_tile % a.stat_rep, which), t);
         }
     }
 }

@@ -289,7 +289,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
     if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
     for (int i = tid; i < G::STAT_FLOATS; i += NTHREADS) stat_lds[i] = 0.f;
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
@@ -430,7 +430,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
             const int ch = (ntile_wg + wn_i * NT) * 16 + c;
-            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ch, (blockIdx.x - b * a.wgs_per_img) % STAT_REPLICAS, which), t);
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ch, a.stat_rep, (blockIdx.x - b * a.wgs_per_img) % a.stat_rep, which), t);
         }
     };
 

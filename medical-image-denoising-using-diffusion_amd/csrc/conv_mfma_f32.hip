@@ -151,7 +151,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) wcur[nt] = wp[nt * 64];
 
     if (a.prologue != PRO_RAW) {
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
         __syncthreads();
     }
     stage_load(0);
@@ -244,7 +244,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + r];
-            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, c0 + wn_i * NT * 16 + c, trem % STAT_REPLICAS, which), t);
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, c0 + wn_i * NT * 16 + c, a.stat_rep, trem % a.stat_rep, which), t);
         }
     }
 }

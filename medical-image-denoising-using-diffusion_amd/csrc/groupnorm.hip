@@ -17,7 +17,7 @@ constexpr int GN_THREADS = 256;
 // grid (rows, B): block `row` sums a contiguous pixel range of sample b per channel in fp64 (products of fp32 values
 // are exact in fp64), rounds the block's sums to fp32 and adds them to tot [B][C][replica][2][3] with exact integer atomics.
 __global__ __launch_bounds__(GN_THREADS)
-void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int HW, int C, int rows) {
+void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int rep, int HW, int C, int rows) {
     extern __shared__ double red[];               // [ppi][C][2]
     const int CQ = C >> 2;
     const int ppi = GN_THREADS / CQ;
@@ -44,8 +44,8 @@ void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ to
     for (int c = tid; c < C; c += GN_THREADS) {
         double cs = 0, css = 0;
         for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
-        stat_atomic_add(stat_slot(tot, b, C, c, row % STAT_REPLICAS, 0), (float)cs);
-        stat_atomic_add(stat_slot(tot, b, C, c, row % STAT_REPLICAS, 1), (float)css);
+        stat_atomic_add(stat_slot(tot, b, C, c, rep, row % rep, 0), (float)cs);
+        stat_atomic_add(stat_slot(tot, b, C, c, rep, row % rep, 1), (float)css);
     }
 }
 
@@ -57,11 +57,11 @@ int chan_partial_rows(int HW, int C) {
     return r;
 }
 
-hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, int C, int rows, hipStream_t s) {
+hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int B, int HW, int C, int rows, hipStream_t s) {
     if (C % 4 || C / 4 > GN_THREADS) return hipErrorInvalidValue;
     const int ppi = GN_THREADS / (C / 4);
     const size_t lds = (size_t)ppi * C * 2 * sizeof(double);
-    hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, tot, HW, C, rows);
+    hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, tot, rep, HW, C, rows);
     return hipGetLastError();
 }
 

@@ -87,6 +87,7 @@ struct Program {
     std::vector<Op> ops;
     size_t bytes = 0, trow_off = 0;
     size_t stats_off = 0, stats_bytes = 0;      // statistics arena: every tensor's totals, zeroed by one memset per forward
+    int stat_rep = 1;                           // copies per channel (against same-address atomic serialisation)
     std::map<std::string, TensorRef> outputs;
 };
 
@@ -574,7 +575,7 @@ struct Builder {
     size_t stats_cur = 0;
     void alloc_stats(TensorRef& t) {
         t.tot_off = stats_cur;
-        stats_cur += ((size_t)B * t.C * STAT_CH_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
+        stats_cur += ((size_t)B * t.C * g->stat_rep * STAT_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
     }
     // per-channel totals for a tensor no MFMA convolution produced
     void ensure_stats(TensorRef& t) {
@@ -608,6 +609,10 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     if (B < 1 || H < div || W < div || H % div || W % div)
         return fail(MI_EINVAL, "H and W must be positive multiples of %d (got %dx%d), B >= 1", div, H, W);
     g->B = B; g->H = H; g->W = W;
+    // ~640 persistent workgroups per launch, i.e. 640 / B per sample, each adding to the totals once: ~48 per copy
+    g->stat_rep = (640 / B + 47) / 48;
+    if (g->stat_rep < 1) g->stat_rep = 1;
+    if (g->stat_rep > STAT_MAX_REPLICAS) g->stat_rep = STAT_MAX_REPLICAS;
     Builder bld{p, g, Bump{}, B};
     g->trow_off = bld.bump.take((size_t)B * sizeof(int));
     int rc;
@@ -843,7 +848,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                                    g->H, g->W, o.dst.C, s);
                 break;
             case OP_CHAN_TOT:
-                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
+                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), g->stat_rep, B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
                 break;
             case OP_CONV: {
                 ConvArgs a{};
@@ -851,7 +856,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.src1 = o.has_s1 ? F(o.s1.off) : nullptr; a.C1 = o.has_s1 ? o.s1.C : 0;
                 a.B = B; a.H = o.s0.H; a.W = o.s0.W; a.OH = o.dst.H; a.OW = o.dst.W;
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
-                a.prologue = o.prologue;
+                a.prologue = o.prologue; a.stat_rep = g->stat_rep;
                 if (o.gn.on) {
                     a.gn_tot0 = T(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : nullptr;
                     a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f; a.gn_hw = o.s0.H * o.s0.W;
@@ -877,7 +882,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 break;
             case OP_OUT: {
                 OutConvArgs a{};
-                a.src = F(o.s0.off); a.gn_tot = T(o.s0.tot_off); a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
+                a.src = F(o.s0.off); a.gn_tot = T(o.s0.tot_off); a.stat_rep = g->stat_rep; a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                 a.w = wd + p->w_out; a.bias = wd + p->b_out;
                 a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
                 a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;

@@ -35,6 +35,7 @@ struct ConvArgs {
     // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
     // the pixels it produced to the totals [B][Cout][replica][2][3] (exact integer atomics, stats_common.h); zeroed per forward
     stat_word* stat_tot;
+    int stat_rep;           // copies per channel of every totals block of this program (stats_common.h), also for gn_tot0/1
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
     int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default)
@@ -77,7 +78,7 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
 // per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
 // sample each add their partial sums to tot [B][C][replica][2][3]
-hipError_t chan_total_launch(const float* src, stat_word* tot, int B, int HW, int C, int rows, hipStream_t s);
+hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
 // ---------------------------------------------------------------- pre/post-processing (prepost.hip)
@@ -103,7 +104,7 @@ hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9
 
 struct OutConvArgs {
     const float* src;       // NHWC [B][H][W][C]
-    const stat_word* gn_tot; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][replica][2][3], affine [C]
+    const stat_word* gn_tot; int stat_rep; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][replica][2][3], affine [C]
     const float* w;         // [ic][9][C]
     const float* bias;      // [ic]
     int B, H, W, C, ic;

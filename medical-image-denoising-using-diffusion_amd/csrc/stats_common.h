@@ -23,14 +23,14 @@ constexpr int GN_GROUPS_C = 8;                    // nn.GroupNorm(8, C) everywhe
 constexpr int STAT_LIMBS = 3;                     // int64 limbs per total
 constexpr int STAT_WORDS = 2 * STAT_LIMBS;        // per replica: sum, sum of squares
 // Same-address atomics serialise at the memory side (~25 ns each, measured: a 640-workgroup launch at batch 1 spent
-// 13-25 us in them), so every channel keeps STAT_REPLICAS copies of its totals; a producer workgroup adds to copy
-// (its index mod STAT_REPLICAS), a consumer adds the copies' limbs (integers: exact, order-free) before converting.
-constexpr int STAT_REPLICAS = 8;
-constexpr int STAT_CH_WORDS = STAT_REPLICAS * STAT_WORDS;     // words per channel: layout [B][C][replica][sum | sumsq][limb]
+// 13-25 us in them), so a channel keeps `rep` copies of its totals (1..STAT_MAX_REPLICAS, chosen per execution program
+// from the batch size: ~48 workgroups per copy); a producer workgroup adds to copy (its index mod rep), a consumer adds
+// the copies' limbs (integers: exact, order-free) before converting.  Layout [B][C][rep][sum | sumsq][limb].
+constexpr int STAT_MAX_REPLICAS = 8;
 typedef unsigned long long stat_word;
 
-__device__ __forceinline__ stat_word* stat_slot(stat_word* tot, size_t b, int C, int c, int replica, int which) {
-    return tot + ((b * C + c) * STAT_REPLICAS + replica) * STAT_WORDS + which * STAT_LIMBS;
+__device__ __forceinline__ stat_word* stat_slot(stat_word* tot, size_t b, int C, int c, int rep, int replica, int which) {
+    return tot + ((b * C + c) * rep + replica) * STAT_WORDS + which * STAT_LIMBS;
 }
 
 // totals[k] += limb k of v * 2^60 (exact for 2^-37 <= |v| < 2^59; smaller magnitudes are truncated towards zero at
@@ -64,14 +64,13 @@ __device__ __forceinline__ double stat_total(const stat_word* limbs) {
     return (double)l0 * 0x1p-60 + (double)l1 * 0x1p-20 + (double)l2 * 0x1p20;       // each limb is exact in fp64 (|l| < 2^53)
 }
 
-// one channel's (sum, sum of squares) from its STAT_REPLICAS copies: 16-byte loads, integer limb sums, one conversion
-__device__ __forceinline__ void stat_channel(const stat_word* __restrict__ p, double& s1, double& s2) {
+// one channel's (sum, sum of squares) from its `rep` copies: 16-byte loads, integer limb sums, one conversion
+__device__ __forceinline__ void stat_channel(const stat_word* __restrict__ p, int rep, double& s1, double& s2) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     stat_word acc[STAT_WORDS];
 #pragma unroll
     for (int i = 0; i < STAT_WORDS; ++i) acc[i] = 0;
-#pragma unroll
-    for (int r = 0; r < STAT_REPLICAS; ++r) {
+    for (int r = 0; r < rep; ++r) {
 #pragma unroll
         for (int i = 0; i < STAT_WORDS; i += 2) {
             const u64x2 v = *reinterpret_cast<const u64x2*>(p + r * STAT_WORDS + i);
@@ -82,13 +81,14 @@ __device__ __forceinline__ void stat_channel(const stat_word* __restrict__ p, do
 }
 
 // GroupNorm scale/shift of sample b into LDS: gnp[c] = mult * rstd * gamma[c], gnp[Cin + c] = mult * (beta[c] - mean * rstd * gamma[c]).
-// tot0 / tot1: totals [B][C0][replica][2][3] / [B][C1][...] of the two concatenated sources (tot1 is not read when C1 == 0);
+// tot0 / tot1: totals [B][C0][rep][2][3] / [B][C1][rep][2][3] of the two concatenated sources (tot1 is not read when C1 == 0);
 // hw = pixels per channel.  Wave w handles groups w, w + nwaves, ...: lane l takes channel g*cg + l (+64, ...), a
 // 64-lane butterfly (commutative adds: every lane ends with the same bits) gives the group sums, mean / rstd in fp64.
 // Visible to the workgroup after its next barrier.  Called by all threads.
-__device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ tot0, int C0, const stat_word* __restrict__ tot1, int C1,
+__device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ tot0, int C0, const stat_word* __restrict__ tot1, int C1, int rep,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                 int hw, int b, float mult, float* gnp, int tid, int nthreads) {
+    const int STAT_CH_WORDS = rep * STAT_WORDS;
     const int Cin = C0 + C1, cg = Cin / GN_GROUPS_C;
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     if (cg <= 64 && GN_GROUPS_C <= 2 * nwaves) {
@@ -101,8 +101,8 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
         double s1a = 0, s2a = 0, s1b = 0, s2b = 0;
         if (on0) { ga0 = gamma[c0]; be0 = beta[c0]; }
         if (on1) { ga1 = gamma[c1]; be1 = beta[c1]; }
-        if (on0) stat_channel((c0 < C0) ? tot0 + ((size_t)b * C0 + c0) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c0 - C0)) * STAT_CH_WORDS, s1a, s2a);
-        if (on1) stat_channel((c1 < C0) ? tot0 + ((size_t)b * C0 + c1) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c1 - C0)) * STAT_CH_WORDS, s1b, s2b);
+        if (on0) stat_channel((c0 < C0) ? tot0 + ((size_t)b * C0 + c0) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c0 - C0)) * STAT_CH_WORDS, rep, s1a, s2a);
+        if (on1) stat_channel((c1 < C0) ? tot0 + ((size_t)b * C0 + c1) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c1 - C0)) * STAT_CH_WORDS, rep, s1b, s2b);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             s1a += __shfl_xor(s1a, off, 64); s2a += __shfl_xor(s2a, off, 64);
@@ -130,7 +130,7 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
         for (int l = lane; l < cg; l += 64) {
             const int c = g * cg + l;
             double c1v, c2v;
-            stat_channel((c < C0) ? tot0 + ((size_t)b * C0 + c) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c - C0)) * STAT_CH_WORDS, c1v, c2v);
+            stat_channel((c < C0) ? tot0 + ((size_t)b * C0 + c) * STAT_CH_WORDS : tot1 + ((size_t)b * C1 + (c - C0)) * STAT_CH_WORDS, rep, c1v, c2v);
             s1 += c1v; s2 += c2v;
         }
 #pragma unroll
