@@ -1,0 +1,349 @@
+// 3x3 stride-1 convolution in f16x3 arithmetic, WAVE-SPECIALISED: the layers that dominate the sampler
+// (/root/reference/Backend/DDIM/DDIMModel.py:118,124 -- both convolutions of every ResidualBlock; the folded
+// ConvTranspose of :211+:241).  Same contract, number format, tile (16 x 8 pixels x 48 couts), weight pack, LDS image
+// and epilogue as conv_mfma_f16x3.hip; what changes is who does what.
+//
+// In the general kernel every wave runs the whole pipeline in turn -- DMA issue, counted wait, barrier, transform
+// (GroupNorm-apply / SiLU / hi-lo split of the staged raw chunk), fragment reads, MFMAs, epilogue -- and its in-kernel
+// stamps show the phases of a workgroup ADDING UP: fragment reads + MFMA are 17-33 % of a workgroup's cycles, the
+// transform 12-28 %, DMA issue 8-22 %, DMA waits 6-20 %; three co-resident workgroups hide only
+// part of it (MFMA pipe 36 % busy).  Here a workgroup is 8 waves:
+//   waves 0-3  CONSUMERS  fragment reads + MFMAs (32 pixels x 48 couts each), epilogue, statistics -- nothing else;
+//   waves 4-7  PRODUCERS  weight ring refills, raw activation chunks TWO chunks ahead (double-buffered raw landing
+//                         zone: ten K-steps, ~5 us, of HBM latency cover instead of one chunk), and the transform of
+//                         chunk c+1 into the OTHER of two MFMA images while the consumers multiply chunk c.
+// One s_barrier per K-step joins the two groups: before it a producer has waited (counted vmcnt) for the step's weights
+// and finished its LDS writes, a consumer has finished reading the previous step's ring slot.  Two such workgroups per
+// CU (70 KB LDS each, <= 128 VGPRs): two MFMA-only waves per SIMD.
+//
+// DMA accounting of a producer wave (PPW weight pieces per step, APW raw pieces per chunk, D = RING-1 steps ahead):
+// step k of a chunk issues W(k+D) and, in step 0, behind it, A(c+2).  When step k waits for W(k), the younger groups are
+// D-1 weight groups plus A(c+2) during steps 1..D (issued after W(k) then, before it afterwards): N = (D-1)*PPW [+ APW].
+// A(c+1), issued a whole chunk earlier, is older than every W waited for in chunk c: it has landed when its transform
+// starts.
+#include "f16x3_common.h"
+#include <cstdlib>
+
+namespace midd {
+
+struct WsGeom {
+    static constexpr int TW = 16, TH = 8, MT = 2, NT = 3, NCONS = 4, NPROD = 4;
+    static constexpr int NTHREADS = (NCONS + NPROD) * 64, PTHREADS = NPROD * 64;
+    static constexpr int IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
+    static constexpr int NSLOT = NPIX * 4;                                     // 16-byte slots (pixel, 4-channel quad) per chunk
+    static constexpr int APW = (NSLOT + PTHREADS - 1) / PTHREADS;              // raw DMA pieces per producer wave and chunk
+    static constexpr int RAW_BYTES = APW * PTHREADS * 16;
+    static constexpr int PLANE = NPIX * 32, IMG_BYTES = 2 * PLANE;
+    static constexpr int WPIECES = NT * 2, PPW = (WPIECES + NPROD - 1) / NPROD, WSLICE = WPIECES * 1024;
+    static constexpr int RING = 3, D = RING - 1, HSTEPS = 5;
+    static constexpr int STAT_FLOATS = NCONS * 2 * NT * 16, ADD_FLOATS = NT * 16;
+    static constexpr int FIXED = 2 * RAW_BYTES + 2 * IMG_BYTES + RING * WSLICE + (STAT_FLOATS + ADD_FLOATS) * 4 + 64;
+    static int lds_bytes(int cin) { return FIXED + 2 * cin * 4; }
+};
+
+__global__ __launch_bounds__(WsGeom::NTHREADS, 4)      // two 8-wave workgroups per CU: <= 128 VGPRs
+void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
+    using G = WsGeom;
+    constexpr int TW = G::TW, TH = G::TH, IW = G::IW, MT = G::MT, NT = G::NT, APW = G::APW, PPW = G::PPW;
+    constexpr int PLANE = G::PLANE, WSLICE = G::WSLICE, RING = G::RING, D = G::D, HSTEPS = G::HSTEPS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const raw0 = lds;                                        // two raw landing zones
+    char* const img0 = raw0 + 2 * G::RAW_BYTES;                    // two MFMA images [hi|lo][halo pixel][16 fp16]
+    char* const wring = img0 + 2 * G::IMG_BYTES;
+    float* const stat_lds = reinterpret_cast<float*>(wring + RING * WSLICE);      // [consumer wave][2][48]
+    float* const add_lds = stat_lds + G::STAT_FLOATS;                              // [48] bias (+ time embedding)
+    float* const gnp = add_lds + G::ADD_FLOATS;                                    // [2][Cin] scale, shift
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= G::NCONS;
+    const int Cin = a.C0 + a.C1, nchunks = Cin >> 4;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / a.wgs_per_img;
+    const int first_tile = blockIdx.x - b * a.wgs_per_img;
+    const int my_tiles = (tiles_per_img - first_tile + a.wgs_per_img - 1) / a.wgs_per_img;
+    const int total_chunks = my_tiles * nchunks;                  // the workgroup's chunk sequence q = 0 .. total_chunks-1
+    const int ntiles_total = a.Cout >> 4, ntile_wg = blockIdx.y * NT;
+
+    // ---- prologue, all 8 waves: GroupNorm scale / shift, bias + time embedding, zeroed statistics ----
+    if (a.prologue != PRO_RAW)
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
+    for (int i = tid; i < G::STAT_FLOATS; i += G::NTHREADS) stat_lds[i] = 0.f;
+    {
+        const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
+        for (int i = tid; i < G::ADD_FLOATS; i += G::NTHREADS) {
+            const int co = ntile_wg * 16 + i;
+            add_lds[i] = a.bias[co] + (a.temb != nullptr ? a.temb[(size_t)trow * a.temb_stride + co] : 0.f);
+        }
+    }
+
+    if (producer) {
+        // =========================================================================== PRODUCERS
+        const int ptid = tid - G::NCONS * 64, pwave = wave - G::NCONS;
+        const int q4 = ptid & 3;                                   // 4-channel quad of the 16-channel chunk
+        // weights: ring refills, cyclic over the tile's steps (the step sequence is the same for every tile)
+        const char* const wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048;
+        const size_t wstep_bytes = (size_t)ntiles_total * 2048;
+        const int steps_per_tile = nchunks * HSTEPS;
+        const int lane16 = lane * 16;
+        int wr_step = 0, wr_slot = 0;
+        const char* wr_src = wbase;
+        auto issue_w = [&]() {
+            char* slot = wring + wr_slot * WSLICE;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                int piece = pwave + i * G::NPROD;
+                if (piece >= G::WPIECES) piece -= G::WPIECES;      // padding duplicate: same bytes, same place
+                dma16(wr_src + piece * 1024 + lane16, slot + piece * 1024);
+            }
+            ++wr_step; wr_src += wstep_bytes;
+            if (wr_step == steps_per_tile) { wr_step = 0; wr_src = wbase; }
+            wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
+        };
+        // activations: slot = (halo pixel, quad); valid[parity] remembers, per landing zone, which of this thread's slots
+        // lie inside the image (the conv pads its NORMALISED input with zeros, so the mask is applied after the transform)
+        unsigned valid[2] = {0u, 0u};
+        auto issue_a = [&](int q) {                                // chunk q of the sequence -> raw[q & 1]
+            const int tile = first_tile + (q / nchunks) * a.wgs_per_img, c = q % nchunks;
+            const int iy0 = (tile / a.tiles_x) * TH - 1, ix0 = (tile % a.tiles_x) * TW - 1;
+            const int ch = (c << 4) + q4 * 4;
+            const float* src; unsigned cs4, coff;
+            if (ch < a.C0) { src = a.src0; cs4 = a.C0 * 4u; coff = ch * 4u; }
+            else           { src = a.src1; cs4 = a.C1 * 4u; coff = (ch - a.C0) * 4u; }
+            const char* base = reinterpret_cast<const char*>(src);
+            char* dst = raw0 + (q & 1) * G::RAW_BYTES;
+            unsigned v = 0u;
+#pragma unroll
+            for (int s = 0; s < APW; ++s) {
+                const int slot = ptid + s * G::PTHREADS;
+                const int pix = min(slot >> 2, G::NPIX - 1);
+                const int iy = pix / IW, ix = pix - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                v |= (in ? 1u : 0u) << s;
+                const unsigned off = in ? (unsigned)((b * a.H + gy) * a.W + gx) : 0u;      // tensors are < 4 GiB (host-checked)
+                dma16(base + off * cs4 + coff, dst + (pwave + s * G::NPROD) * 1024);
+            }
+            valid[q & 1] = v;
+        };
+        auto transform_slot = [&](int q, int s) {                  // raw[q & 1] slot s -> img[q & 1]
+            const int slot = ptid + s * G::PTHREADS;
+            if (slot >= G::NSLOT) return;
+            const int ch = ((q % nchunks) << 4) + q4 * 4;
+            f32x4 sc = {RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (a.prologue != PRO_RAW) {                           // 2^s folded into the affine by the prologue
+                sc = *reinterpret_cast<const f32x4*>(gnp + ch);
+                sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch);
+            }
+            f32x4 v = *reinterpret_cast<const f32x4*>(raw0 + (q & 1) * G::RAW_BYTES + slot * 16);
+            v = v * sc + sh;
+            if (a.prologue == PRO_GN_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
+                    v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+            }
+            if (!((valid[q & 1] >> s) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            half4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h = (_Float16)v[e];
+                hi[e] = h;
+                lo[e] = (_Float16)(v[e] - (float)h);
+            }
+            char* base = img0 + (q & 1) * G::IMG_BYTES + (slot >> 2) * 32 + q4 * 8;
+            *reinterpret_cast<half4*>(base) = hi;
+            *reinterpret_cast<half4*>(base + PLANE) = lo;
+        };
+
+        issue_a(0);
+        if (total_chunks > 1) issue_a(1);
+#pragma unroll
+        for (int i = 0; i < D; ++i) issue_w();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // [P1] raw chunks 0 / 1, weights 0..D-1, gnp, add, stats visible
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < APW; ++s) transform_slot(0, s);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // [P2] image of chunk 0 published
+        asm volatile("" ::: "memory");
+
+        for (int q = 0; q < total_chunks; ++q) {
+            const bool more1 = q + 1 < total_chunks, more2 = q + 2 < total_chunks;
+#pragma unroll
+            for (int k = 0; k < HSTEPS; ++k) {
+                // W(k) of this chunk has landed; all LDS writes of the previous step (the next image) are done
+                if (more2 && k >= 1 && k <= D) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * PPW + APW) : "memory");
+                else                           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * PPW) : "memory");
+                __builtin_amdgcn_s_barrier();                      // step barrier (consumers: done with the previous ring slot / image)
+                asm volatile("" ::: "memory");
+                issue_w();
+                if (k == 0 && more2) issue_a(q + 2);               // raw[q & 1]: chunk q was transformed during chunk q-1
+                if (more1) {                                        // chunk q+1 -> the image the consumers are NOT reading: one slot per step
+                    if (k < APW) transform_slot(q + 1, k);
+                    if (k == HSTEPS - 1) { for (int s = HSTEPS; s < APW; ++s) transform_slot(q + 1, s); }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weight refills issued past the last step
+        __builtin_amdgcn_s_barrier();                              // [E1] consumers: statistics rows complete
+        return;
+    }
+
+    // =============================================================================== CONSUMERS
+    const int p16 = lane & 15, kq = lane >> 4;
+    int frag_base[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pp = (wave * MT + mt) * 16 + p16;
+        const int py = pp / TW, px = pp - py * TW;
+        frag_base[mt] = (py * IW + px) * 32 + (kq & 1) * 16;
+    }
+    const int wfrag_off = lane * 16;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+    auto epilogue = [&](int tile) {
+        const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
+        f32x4 tsum[NT], tsq[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int co = (ntile_wg + nt) * 16 + kq * 4;
+            const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int pp = (wave * MT + mt) * 16 + p16;
+                const int py = pp / TW, px = pp - py * TW;
+                const int oy = oy0 + py, ox = ox0 + px;
+                if (oy < a.OH && ox < a.OW) {
+                    const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
+                    f32x4 v = acc[mt][nt] * a.out_scale + add;
+                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+                    *reinterpret_cast<f32x4*>(a.out + o) = v;
+                    tsum[nt] += v; tsq[nt] += v * v;
+                }
+                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (a.stat_tot != nullptr) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { tsum[nt][e] = row16_sum(tsum[nt][e]); tsq[nt][e] = row16_sum(tsq[nt][e]); }
+                if (p16 == 0) {
+                    f32x4* ps = reinterpret_cast<f32x4*>(my_stat + nt * 16);
+                    f32x4* pq = reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16);
+                    *ps = *ps + tsum[nt];
+                    *pq = *pq + tsq[nt];
+                }
+            }
+        }
+    };
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // [P1]
+    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // [P2] image of chunk 0 readable
+    asm volatile("" ::: "memory");
+
+    int rd_slot = 0;
+    for (int q = 0; q < total_chunks; ++q) {
+        const char* img = img0 + (q & 1) * G::IMG_BYTES;
+#pragma unroll
+        for (int k = 0; k < HSTEPS; ++k) {
+            const int t0 = 2 * k, t1 = (2 * k + 1 < 9) ? 2 * k + 1 : 0;          // padded half has zero weights
+            const int o0 = ((t0 / 3) * IW + (t0 % 3)) * 32, o1 = ((t1 / 3) * IW + (t1 % 3)) * 32;
+            const int to = (kq >> 1) ? o1 : o0;
+            half8 xh[MT], xl[MT];
+            if (k != 0) {                       // the chunk's image was published at step 0's barrier: request it ahead of this one
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    xh[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to);
+                    xl[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to + PLANE);
+                }
+            }
+            __builtin_amdgcn_s_barrier();       // the step's weights (and at k == 0 the chunk's image) are in LDS
+            asm volatile("" ::: "memory");
+            if (k == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    xh[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to);
+                    xl[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to + PLANE);
+                }
+            }
+            const char* wslot = wring + rd_slot * WSLICE + wfrag_off;
+            rd_slot = (rd_slot + 1 == RING) ? 0 : rd_slot + 1;
+            half8 wh[NT], wl[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
+                wl[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+            // every LDS read of this step has returned (the MFMAs consumed them) before the wave reaches the next barrier
+        }
+        if ((q + 1) % nchunks == 0) epilogue(first_tile + (q / nchunks) * a.wgs_per_img);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // [E1] all consumer waves' statistics rows are in LDS
+    asm volatile("" ::: "memory");
+    if (a.stat_tot != nullptr) {
+        constexpr int ROWF = 2 * NT * 16;
+        for (int i = tid; i < ROWF; i += G::NCONS * 64) {
+            const int which = i / (NT * 16), c = i - which * (NT * 16);
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < G::NCONS; ++m) t += stat_lds[m * ROWF + i];
+            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ntile_wg * 16 + c, a.stat_rep, first_tile % a.stat_rep, which), t);
+        }
+    }
+}
+
+bool conv3x3_ws_tile_ok(const ConvTile& t, int C0, int C1, int Cout) {
+    static const bool on = !(getenv("MIDD_WS") && atoi(getenv("MIDD_WS")) == 0);
+    return on && t.ks == 3 && t.stride == 1 && t.tw == 16 && t.mt == 2 && t.nt == 3 && t.wm == 4 && t.wn == 1 &&
+           Cout % 48 == 0 && (C0 % 16) == 0 && (C1 % 16) == 0 && WsGeom::lds_bytes(C0 + C1) <= 80 * 1024;
+}
+
+hipError_t conv3x3_ws_launch(const ConvArgs& a0, hipStream_t s) {
+    using G = WsGeom;
+    ConvArgs a = a0;
+    a.tiles_x = (a.OW + G::TW - 1) / G::TW;
+    a.tiles_y = (a.OH + G::TH - 1) / G::TH;
+    const int ny = a.Cout / (G::NT * 16);
+    // two 8-wave workgroups per CU
+    a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny, a.persist_wgs ? (a.persist_wgs * 2) / 3 : 512);
+    if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;      // 32-bit DMA offsets
+    const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
+    static int raised = 0;
+    if (lds_bytes > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws_f16x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        raised = lds_bytes;
+    }
+    hipLaunchKernelGGL(conv3x3_ws_f16x3_kernel, dim3(a.B * a.wgs_per_img, ny), dim3(G::NTHREADS), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace midd
