@@ -16,11 +16,18 @@
 // and finished its LDS writes, a consumer has finished reading the previous step's ring slot.  Two such workgroups per
 // CU (70 KB LDS each, <= 128 VGPRs): two MFMA-only waves per SIMD.
 //
-// DMA accounting of a producer wave (PPW weight pieces per step, APW raw pieces per chunk, D = RING-1 steps ahead):
-// step k of a chunk issues W(k+D) and, in step 0, behind it, A(c+2).  When step k waits for W(k), the younger groups are
-// D-1 weight groups plus A(c+2) during steps 1..D (issued after W(k) then, before it afterwards): N = (D-1)*PPW [+ APW].
-// A(c+1), issued a whole chunk earlier, is older than every W waited for in chunk c: it has landed when its transform
-// starts.
+// Weights: L2 -> LDS latency under load is 1-2 thousand cycles, a K-step is ~500, and LDS has no room for a deeper
+// ring -- so the producers prefetch the weights a whole chunk (5 steps) ahead INTO THEIR OWN REGISTERS
+// (global_load_dwordx4, one 1 KiB piece per wave instruction: 40 VGPRs that a producer does not otherwise need) and copy
+// a step's pieces into the 3-slot LDS ring two steps before the consumers read them.  (The first version refilled
+// the ring by LDS-DMA two steps ahead like the general kernel: every step then waited ~1800 cycles for its weights.)
+//
+// vmcnt accounting of a producer wave (PPW weight loads per step, APW raw DMA pieces per chunk, always issued -- a dummy
+// chunk past the end -- so the count is constant): step k of chunk q, after the barrier, waits for regs[k] (requested in
+// step k of chunk q-1), copies them to the ring, then requests [step 0: the raw chunk q+2, then] regs[k] again for the
+// same step of the next chunk.  Younger than the load waited for: the 4 weight groups of the steps in between, plus the
+// raw chunk of this chunk's step 0 when k >= 1:  N = 4*PPW (+ APW).  Raw chunk q+1 (step 0 of chunk q-1) is older than
+// regs[0] of that step, so it has landed when step (q, 0) starts transforming it.
 #include "f16x3_common.h"
 #include <cstdlib>
 
@@ -81,29 +88,44 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         // =========================================================================== PRODUCERS
         const int ptid = tid - G::NCONS * 64, pwave = wave - G::NCONS;
         const int q4 = ptid & 3;                                   // 4-channel quad of the 16-channel chunk
-        // weights: ring refills, cyclic over the tile's steps (the step sequence is the same for every tile)
+        // weights: the step sequence is the same for every tile, walked cyclically
         const char* const wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048;
         const size_t wstep_bytes = (size_t)ntiles_total * 2048;
         const int steps_per_tile = nchunks * HSTEPS;
         const int lane16 = lane * 16;
-        int wr_step = 0, wr_slot = 0;
-        const char* wr_src = wbase;
-        auto issue_w = [&]() {
+        int piece_off[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            int piece = pwave + i * G::NPROD;
+            if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place
+            piece_off[i] = piece * 1024 + lane16;
+        }
+        int wr_slot = 0;                                           // ring slot the next copy goes to
+        int ld_step = 0;                                           // tile-relative step the next register load fetches
+        f32x4 wreg[HSTEPS][PPW];
+        auto dma_w = [&]() {                                       // prologue only: steps 0..D-1 straight into the ring
+            const char* src = wbase + (size_t)ld_step * wstep_bytes;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) dma16(src + piece_off[i], wring + wr_slot * WSLICE + piece_off[i] - lane16);
+            ld_step = (ld_step + 1 == steps_per_tile) ? 0 : ld_step + 1;
+            wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
+        };
+        auto load_w = [&](f32x4 (&r)[PPW]) {
+            const char* src = wbase + (size_t)ld_step * wstep_bytes;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) r[i] = *reinterpret_cast<const f32x4*>(src + piece_off[i]);
+            ld_step = (ld_step + 1 == steps_per_tile) ? 0 : ld_step + 1;
+        };
+        auto store_w = [&](const f32x4 (&r)[PPW]) {
             char* slot = wring + wr_slot * WSLICE;
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                int piece = pwave + i * G::NPROD;
-                if (piece >= G::WPIECES) piece -= G::WPIECES;      // padding duplicate: same bytes, same place
-                dma16(wr_src + piece * 1024 + lane16, slot + piece * 1024);
-            }
-            ++wr_step; wr_src += wstep_bytes;
-            if (wr_step == steps_per_tile) { wr_step = 0; wr_src = wbase; }
+            for (int i = 0; i < PPW; ++i) *reinterpret_cast<f32x4*>(slot + piece_off[i]) = r[i];
             wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
         };
         // activations: slot = (halo pixel, quad); valid[parity] remembers, per landing zone, which of this thread's slots
         // lie inside the image (the conv pads its NORMALISED input with zeros, so the mask is applied after the transform)
         unsigned valid[2] = {0u, 0u};
-        auto issue_a = [&](int q) {                                // chunk q of the sequence -> raw[q & 1]
+        auto issue_a = [&](int q, int parity) {                    // chunk q of the sequence -> raw[parity]
             const int tile = first_tile + (q / nchunks) * a.wgs_per_img, c = q % nchunks;
             const int iy0 = (tile / a.tiles_x) * TH - 1, ix0 = (tile % a.tiles_x) * TW - 1;
             const int ch = (c << 4) + q4 * 4;
@@ -111,7 +133,7 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             if (ch < a.C0) { src = a.src0; cs4 = a.C0 * 4u; coff = ch * 4u; }
             else           { src = a.src1; cs4 = a.C1 * 4u; coff = (ch - a.C0) * 4u; }
             const char* base = reinterpret_cast<const char*>(src);
-            char* dst = raw0 + (q & 1) * G::RAW_BYTES;
+            char* dst = raw0 + parity * G::RAW_BYTES;
             unsigned v = 0u;
 #pragma unroll
             for (int s = 0; s < APW; ++s) {
@@ -124,7 +146,7 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
                 const unsigned off = in ? (unsigned)((b * a.H + gy) * a.W + gx) : 0u;      // tensors are < 4 GiB (host-checked)
                 dma16(base + off * cs4 + coff, dst + (pwave + s * G::NPROD) * 1024);
             }
-            valid[q & 1] = v;
+            valid[parity] = v;
         };
         auto transform_slot = [&](int q, int s) {                  // raw[q & 1] slot s -> img[q & 1]
             const int slot = ptid + s * G::PTHREADS;
@@ -155,10 +177,12 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             *reinterpret_cast<half4*>(base + PLANE) = lo;
         };
 
-        issue_a(0);
-        if (total_chunks > 1) issue_a(1);
+        issue_a(0, 0);
+        issue_a(min(1, total_chunks - 1), 1);
 #pragma unroll
-        for (int i = 0; i < D; ++i) issue_w();
+        for (int i = 0; i < D; ++i) dma_w();                       // steps 0..D-1 -> ring slots 0..D-1
+#pragma unroll
+        for (int k = 0; k < HSTEPS; ++k) load_w(wreg[k]);          // steps D..D+4 -> registers
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // [P1] raw chunks 0 / 1, weights 0..D-1, gnp, add, stats visible
         asm volatile("" ::: "memory");
@@ -169,23 +193,24 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         asm volatile("" ::: "memory");
 
         for (int q = 0; q < total_chunks; ++q) {
-            const bool more1 = q + 1 < total_chunks, more2 = q + 2 < total_chunks;
+            const bool more1 = q + 1 < total_chunks;
 #pragma unroll
             for (int k = 0; k < HSTEPS; ++k) {
-                // W(k) of this chunk has landed; all LDS writes of the previous step (the next image) are done
-                if (more2 && k >= 1 && k <= D) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * PPW + APW) : "memory");
-                else                           asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 1) * PPW) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the previous step's ring copy and image writes are done
                 __builtin_amdgcn_s_barrier();                      // step barrier (consumers: done with the previous ring slot / image)
                 asm volatile("" ::: "memory");
-                issue_w();
-                if (k == 0 && more2) issue_a(q + 2);               // raw[q & 1]: chunk q was transformed during chunk q-1
-                if (more1) {                                        // chunk q+1 -> the image the consumers are NOT reading: one slot per step
+                if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
+                else        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW + APW) : "memory");
+                store_w(wreg[k]);                                  // step (q, k) + D -> ring: read two barriers from now
+                if (k == 0) issue_a(min(q + 2, total_chunks - 1), q & 1);   // raw[q & 1]: chunk q was transformed during chunk q-1 (past the end: a dummy)
+                load_w(wreg[k]);                                   // the same step of the next chunk
+                if (more1) {                                       // chunk q+1 -> the image the consumers are NOT reading: one slot per step
                     if (k < APW) transform_slot(q + 1, k);
                     if (k == HSTEPS - 1) { for (int s = HSTEPS; s < APW; ++s) transform_slot(q + 1, s); }
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the weight refills issued past the last step
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the prefetches issued past the last step
         __builtin_amdgcn_s_barrier();                              // [E1] consumers: statistics rows complete
         return;
     }
