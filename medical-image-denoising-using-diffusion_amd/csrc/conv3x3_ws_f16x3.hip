@@ -12,14 +12,18 @@
 //   waves 4-7  PRODUCERS  weight ring refills, raw activation chunks TWO chunks ahead (double-buffered raw landing
 //                         zone: ten K-steps, ~5 us, of HBM latency cover instead of one chunk), and the transform of
 //                         chunk c+1 into the OTHER of two MFMA images while the consumers multiply chunk c.
-// One s_barrier per K-step joins the two groups: before it a producer has waited (counted vmcnt) for the step's weights
-// and finished its LDS writes, a consumer has finished reading the previous step's ring slot.  Two such workgroups per
-// CU (70 KB LDS each, <= 128 VGPRs): two MFMA-only waves per SIMD.
+// One s_barrier per K-step joins the two groups, and nobody waits for its own latest LDS traffic at it: a producer only
+// guarantees that what it wrote in the step BEFORE the previous one is complete (LDS operations retire in order: a
+// counted lgkmcnt that leaves the previous step's operations outstanding), so a step's ring copy (three steps ahead of
+// its use, RING = 4) and image writes (finished two steps before the chunk boundary) are never on the critical path;
+// a consumer reads the NEXT step's weight fragments right after the barrier and multiplies with the ones it read a
+// step earlier (register double buffer), its activation fragments are requested ahead of the barrier.  Two such
+// workgroups per CU (77 KB LDS each, <= 128 VGPRs): two MFMA-only waves per SIMD.
 //
 // Weights: L2 -> LDS latency under load is 1-2 thousand cycles, a K-step is ~500, and LDS has no room for a deeper
 // ring -- so the producers prefetch the weights a whole chunk (5 steps) ahead INTO THEIR OWN REGISTERS
 // (global_load_dwordx4, one 1 KiB piece per wave instruction: 40 VGPRs that a producer does not otherwise need) and copy
-// a step's pieces into the 3-slot LDS ring two steps before the consumers read them.  (The first version refilled
+// a step's pieces into the 4-slot LDS ring three steps before the consumers multiply with them.  (The first version refilled
 // the ring by LDS-DMA two steps ahead like the general kernel: every step then waited ~1800 cycles for its weights.)
 //
 // vmcnt accounting of a producer wave (PPW weight loads per step, APW raw DMA pieces per chunk, always issued -- a dummy
@@ -29,9 +33,27 @@
 // raw chunk of this chunk's step 0 when k >= 1:  N = 4*PPW (+ APW).  Raw chunk q+1 (step 0 of chunk q-1) is older than
 // regs[0] of that step, so it has landed when step (q, 0) starts transforming it.
 #include "f16x3_common.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace midd {
+
+// Diagnostic build only (-DMIDD_CONV_TIMING, `make timing`): s_memtime stamps of consumer wave 0 and producer wave 4 of
+// every workgroup, summed per launch.  Never compiled into libmidd.so.
+#ifdef MIDD_CONV_TIMING
+enum { WT_C_BARRIER, WT_C_COMPUTE, WT_C_EPI, WT_C_TOTAL, WT_P_BARRIER, WT_P_WAITVM, WT_P_WORK, WT_P_TOTAL, WT_STEPS, WT_WGS, WT_N };
+__device__ unsigned long long g_ws_timing[WT_N];
+__device__ __forceinline__ unsigned long long wt_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define WT_DECL unsigned long long wt_acc[WT_N] = {}; unsigned long long wt_last = wt_stamp(); const unsigned long long wt_t0 = wt_last;
+#define WT(k) { const unsigned long long t_ = wt_stamp(); wt_acc[k] += t_ - wt_last; wt_last = t_; }
+#else
+#define WT_DECL
+#define WT(k)
+#endif
 
 struct WsGeom {
     static constexpr int TW = 16, TH = 8, MT = 2, NT = 3, NCONS = 4, NPROD = 4;
@@ -42,7 +64,7 @@ struct WsGeom {
     static constexpr int RAW_BYTES = APW * PTHREADS * 16;
     static constexpr int PLANE = NPIX * 32, IMG_BYTES = 2 * PLANE;
     static constexpr int WPIECES = NT * 2, PPW = (WPIECES + NPROD - 1) / NPROD, WSLICE = WPIECES * 1024;
-    static constexpr int RING = 3, D = RING - 1, HSTEPS = 5;
+    static constexpr int RING = 4, D = RING - 1, HSTEPS = 5;
     static constexpr int STAT_FLOATS = NCONS * 2 * NT * 16, ADD_FLOATS = NT * 16;
     static constexpr int FIXED = 2 * RAW_BYTES + 2 * IMG_BYTES + RING * WSLICE + (STAT_FLOATS + ADD_FLOATS) * 4 + 64;
     static int lds_bytes(int cin) { return FIXED + 2 * cin * 4; }
@@ -125,6 +147,12 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         // activations: slot = (halo pixel, quad); valid[parity] remembers, per landing zone, which of this thread's slots
         // lie inside the image (the conv pads its NORMALISED input with zeros, so the mask is applied after the transform)
         unsigned valid[2] = {0u, 0u};
+        int s_iy[APW], s_ix[APW];                                  // this thread's halo pixels (the same in every tile)
+#pragma unroll
+        for (int s = 0; s < APW; ++s) {
+            const int pix = min((ptid + s * G::PTHREADS) >> 2, G::NPIX - 1);
+            s_iy[s] = pix / IW; s_ix[s] = pix - s_iy[s] * IW;
+        }
         auto issue_a = [&](int q, int parity) {                    // chunk q of the sequence -> raw[parity]
             const int tile = first_tile + (q / nchunks) * a.wgs_per_img, c = q % nchunks;
             const int iy0 = (tile / a.tiles_x) * TH - 1, ix0 = (tile % a.tiles_x) * TW - 1;
@@ -137,10 +165,7 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             unsigned v = 0u;
 #pragma unroll
             for (int s = 0; s < APW; ++s) {
-                const int slot = ptid + s * G::PTHREADS;
-                const int pix = min(slot >> 2, G::NPIX - 1);
-                const int iy = pix / IW, ix = pix - iy * IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
+                const int gy = iy0 + s_iy[s], gx = ix0 + s_ix[s];
                 const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 v |= (in ? 1u : 0u) << s;
                 const unsigned off = in ? (unsigned)((b * a.H + gy) * a.W + gx) : 0u;      // tensors are < 4 GiB (host-checked)
@@ -192,25 +217,36 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();                              // [P2] image of chunk 0 published
         asm volatile("" ::: "memory");
 
+        WT_DECL
         for (int q = 0; q < total_chunks; ++q) {
             const bool more1 = q + 1 < total_chunks;
 #pragma unroll
             for (int k = 0; k < HSTEPS; ++k) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the previous step's ring copy and image writes are done
+                // everything but the previous step's LDS operations (ring copy: 2 writes; transform: 1 read + 2 writes in
+                // steps 0..APW-1) is complete -- LDS operations retire in order
+                if (k >= 1 && k <= APW) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                else                    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                WT(WT_P_WORK)
                 __builtin_amdgcn_s_barrier();                      // step barrier (consumers: done with the previous ring slot / image)
                 asm volatile("" ::: "memory");
+                WT(WT_P_BARRIER)
                 if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
                 else        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW + APW) : "memory");
-                store_w(wreg[k]);                                  // step (q, k) + D -> ring: read two barriers from now
+                WT(WT_P_WAITVM)
+                store_w(wreg[k]);                                  // step (q, k) + D -> ring: first read two barriers from now
                 if (k == 0) issue_a(min(q + 2, total_chunks - 1), q & 1);   // raw[q & 1]: chunk q was transformed during chunk q-1 (past the end: a dummy)
                 load_w(wreg[k]);                                   // the same step of the next chunk
-                if (more1) {                                       // chunk q+1 -> the image the consumers are NOT reading: one slot per step
-                    if (k < APW) transform_slot(q + 1, k);
-                    if (k == HSTEPS - 1) { for (int s = HSTEPS; s < APW; ++s) transform_slot(q + 1, s); }
-                }
+                static_assert(APW <= HSTEPS - 2, "the next image must be complete two steps before the chunk boundary");
+                if (more1 && k < APW) transform_slot(q + 1, k);    // chunk q+1 -> the image the consumers are NOT reading: one slot per step
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the prefetches issued past the last step
+#ifdef MIDD_CONV_TIMING
+        if (tid == G::NCONS * 64) {
+            wt_acc[WT_P_TOTAL] = wt_stamp() - wt_t0;
+            for (int k = WT_P_BARRIER; k <= WT_P_TOTAL; ++k) atomicAdd(&g_ws_timing[k], wt_acc[k]);
+        }
+#endif
         __builtin_amdgcn_s_barrier();                              // [E1] consumers: statistics rows complete
         return;
     }
@@ -277,7 +313,15 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
     __builtin_amdgcn_s_barrier();                                  // [P2] image of chunk 0 readable
     asm volatile("" ::: "memory");
 
-    int rd_slot = 0;
+    // weight fragments: the step being multiplied (wh_c / wl_c) and, read right after the step barrier, the next one
+    half8 wh_c[NT], wl_c[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        wh_c[nt] = *reinterpret_cast<const half8*>(wring + wfrag_off + nt * 2048);
+        wl_c[nt] = *reinterpret_cast<const half8*>(wring + wfrag_off + nt * 2048 + 1024);
+    }
+    int rd_slot = 1;                            // ring slot of the NEXT step
+    WT_DECL
     for (int q = 0; q < total_chunks; ++q) {
         const char* img = img0 + (q & 1) * G::IMG_BYTES;
 #pragma unroll
@@ -285,50 +329,52 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             const int t0 = 2 * k, t1 = (2 * k + 1 < 9) ? 2 * k + 1 : 0;          // padded half has zero weights
             const int o0 = ((t0 / 3) * IW + (t0 % 3)) * 32, o1 = ((t1 / 3) * IW + (t1 % 3)) * 32;
             const int to = (kq >> 1) ? o1 : o0;
+            // the chunk's image is complete two steps before the chunk starts: its fragments are requested ahead of the barrier
             half8 xh[MT], xl[MT];
-            if (k != 0) {                       // the chunk's image was published at step 0's barrier: request it ahead of this one
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    xh[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to);
-                    xl[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to + PLANE);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                xh[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to);
+                xl[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to + PLANE);
             }
-            __builtin_amdgcn_s_barrier();       // the step's weights (and at k == 0 the chunk's image) are in LDS
+            WT(WT_C_COMPUTE)
+            __builtin_amdgcn_s_barrier();       // the producers' copies from two steps ago (the next step's weights) are complete
             asm volatile("" ::: "memory");
-            if (k == 0) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    xh[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to);
-                    xl[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to + PLANE);
-                }
-            }
+            WT(WT_C_BARRIER)
             const char* wslot = wring + rd_slot * WSLICE + wfrag_off;
             rd_slot = (rd_slot + 1 == RING) ? 0 : rd_slot + 1;
-            half8 wh[NT], wl[NT];
+            half8 wh_n[NT], wl_n[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
-                wl[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
+                wh_n[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
+                wl_n[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh_c[nt], xh[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xl[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh_c[nt], xl[mt], acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
-            // every LDS read of this step has returned (the MFMAs consumed them) before the wave reaches the next barrier
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl_c[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { wh_c[nt] = wh_n[nt]; wl_c[nt] = wl_n[nt]; }
         }
-        if ((q + 1) % nchunks == 0) epilogue(first_tile + (q / nchunks) * a.wgs_per_img);
+        if ((q + 1) % nchunks == 0) { WT(WT_C_COMPUTE) epilogue(first_tile + (q / nchunks) * a.wgs_per_img); WT(WT_C_EPI) }
     }
+#ifdef MIDD_CONV_TIMING
+    if (tid == 0) {
+        wt_acc[WT_C_TOTAL] = wt_stamp() - wt_t0; wt_acc[WT_STEPS] = (unsigned long long)total_chunks * HSTEPS; wt_acc[WT_WGS] = 1;
+        for (int k = 0; k <= WT_C_TOTAL; ++k) atomicAdd(&g_ws_timing[k], wt_acc[k]);
+        atomicAdd(&g_ws_timing[WT_STEPS], wt_acc[WT_STEPS]); atomicAdd(&g_ws_timing[WT_WGS], wt_acc[WT_WGS]);
+    }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // [E1] all consumer waves' statistics rows are in LDS
     asm volatile("" ::: "memory");
@@ -343,6 +389,23 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         }
     }
 }
+
+#ifdef MIDD_CONV_TIMING
+extern "C" __attribute__((visibility("default"))) void mi_debug_ws_timing_dump(const char* tag) {
+    unsigned long long h[WT_N];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ws_timing), sizeof h);
+    const double steps = (double)h[WT_STEPS], wgs = (double)h[WT_WGS];
+    if (wgs > 0)
+        printf("%-40s wgs %6.0f steps/wg %5.1f | consumer cyc/step: barrier %6.0f compute %6.0f | epilogue/wg %7.0f total/wg %8.0f | "
+               "producer cyc/step: barrier %6.0f waitvm %6.0f work %6.0f total/wg %8.0f\n", tag, wgs, steps / wgs,
+               h[WT_C_BARRIER] / steps, h[WT_C_COMPUTE] / steps, h[WT_C_EPI] / wgs, h[WT_C_TOTAL] / wgs,
+               h[WT_P_BARRIER] / steps, h[WT_P_WAITVM] / steps, h[WT_P_WORK] / steps, h[WT_P_TOTAL] / wgs);
+    unsigned long long z[WT_N] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_timing), z, sizeof z);
+    fflush(stdout);
+}
+#endif
 
 bool conv3x3_ws_tile_ok(const ConvTile& t, int C0, int C1, int Cout) {
     static const bool on = !(getenv("MIDD_WS") && atoi(getenv("MIDD_WS")) == 0);
