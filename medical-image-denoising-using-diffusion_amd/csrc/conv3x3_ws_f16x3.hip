@@ -20,18 +20,21 @@
 // step earlier (register double buffer), its activation fragments are requested ahead of the barrier.  Two such
 // workgroups per CU (77 KB LDS each, <= 128 VGPRs): two MFMA-only waves per SIMD.
 //
-// Weights: L2 -> LDS latency under load is 1-2 thousand cycles, a K-step is ~500, and LDS has no room for a deeper
-// ring -- so the producers prefetch the weights a whole chunk (5 steps) ahead INTO THEIR OWN REGISTERS
-// (global_load_dwordx4, one 1 KiB piece per wave instruction: 40 VGPRs that a producer does not otherwise need) and copy
-// a step's pieces into the 4-slot LDS ring three steps before the consumers multiply with them.  (The first version refilled
-// the ring by LDS-DMA two steps ahead like the general kernel: every step then waited ~1800 cycles for its weights.)
+// Weights go global -> LDS by LDS-DMA into a 4-slot ring, three steps ahead.  (Prefetching them a whole chunk ahead
+// into producer registers was tried: hipcc guards every use of a register filled by a global load with vmcnt(0) once
+// opaque asm waits are around, which drains the raw-chunk DMA every step; and the ablations below say the weight
+// latency is not what limits this kernel.)
 //
-// vmcnt accounting of a producer wave (PPW weight loads per step, APW raw DMA pieces per chunk, always issued -- a dummy
-// chunk past the end -- so the count is constant): step k of chunk q, after the barrier, waits for regs[k] (requested in
-// step k of chunk q-1), copies them to the ring, then requests [step 0: the raw chunk q+2, then] regs[k] again for the
-// same step of the next chunk.  Younger than the load waited for: the 4 weight groups of the steps in between, plus the
-// raw chunk of this chunk's step 0 when k >= 1:  N = 4*PPW (+ APW).  Raw chunk q+1 (step 0 of chunk q-1) is older than
-// regs[0] of that step, so it has landed when step (q, 0) starts transforming it.
+// vmcnt accounting of a producer wave (PPW weight pieces per step, APW raw pieces per chunk, D = 3 steps ahead): step k of
+// chunk q issues, after its barrier, W(s+D) and -- in step 0, behind it -- the raw chunk q+2.  The consumers read W(s+1)
+// right after barrier s, so before that barrier the producer waits for W(s+1), issued two steps earlier: younger than it
+// are W(s+2) and, when one of those two steps was a step 0 (k = 1, 2), the raw chunk: N = PPW (+ APW).  Raw chunk q+1,
+// issued a whole chunk earlier, is older than anything waited for in chunk q: it has landed when its transform starts.
+//
+// Ablations (diagnostic builds, wrong results; whole sampler, B = 8, unsplit, ms in this kernel per denoise call):
+// as is 150.9 | no SiLU 142.7 | ONE MFMA pass instead of three 143.2 | no transform in the loop 121.3 | no per-tile
+// epilogue 101.5 -- the kernel is bound by its memory / synchronisation skeleton, the epilogue and the transform, not
+// by the matrix pipe.
 #include "f16x3_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -122,26 +125,14 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place
             piece_off[i] = piece * 1024 + lane16;
         }
-        int wr_slot = 0;                                           // ring slot the next copy goes to
-        int ld_step = 0;                                           // tile-relative step the next register load fetches
-        f32x4 wreg[HSTEPS][PPW];
-        auto dma_w = [&]() {                                       // prologue only: steps 0..D-1 straight into the ring
-            const char* src = wbase + (size_t)ld_step * wstep_bytes;
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) dma16(src + piece_off[i], wring + wr_slot * WSLICE + piece_off[i] - lane16);
-            ld_step = (ld_step + 1 == steps_per_tile) ? 0 : ld_step + 1;
-            wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
-        };
-        auto load_w = [&](f32x4 (&r)[PPW]) {
-            const char* src = wbase + (size_t)ld_step * wstep_bytes;
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) r[i] = *reinterpret_cast<const f32x4*>(src + piece_off[i]);
-            ld_step = (ld_step + 1 == steps_per_tile) ? 0 : ld_step + 1;
-        };
-        auto store_w = [&](const f32x4 (&r)[PPW]) {
+        int wr_slot = 0, wr_step = 0;                              // ring slot / tile-relative step of the next refill
+        const char* wr_src = wbase;
+        auto issue_w = [&]() {
             char* slot = wring + wr_slot * WSLICE;
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) *reinterpret_cast<f32x4*>(slot + piece_off[i]) = r[i];
+            for (int i = 0; i < PPW; ++i) dma16(wr_src + piece_off[i], slot + piece_off[i] - lane16);
+            ++wr_step; wr_src += wstep_bytes;
+            if (wr_step == steps_per_tile) { wr_step = 0; wr_src = wbase; }
             wr_slot = (wr_slot + 1 == RING) ? 0 : wr_slot + 1;
         };
         // activations: slot = (halo pixel, quad); valid[parity] remembers, per landing zone, which of this thread's slots
@@ -184,7 +175,11 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             }
             f32x4 v = *reinterpret_cast<const f32x4*>(raw0 + (q & 1) * G::RAW_BYTES + slot * 16);
             v = v * sc + sh;
+#if defined(WS_ABL) && WS_ABL == 1      // ablation (wrong results): no SiLU
+            if (false) {
+#else
             if (a.prologue == PRO_GN_SILU) {
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
                     v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
@@ -205,9 +200,7 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         issue_a(0, 0);
         issue_a(min(1, total_chunks - 1), 1);
 #pragma unroll
-        for (int i = 0; i < D; ++i) dma_w();                       // steps 0..D-1 -> ring slots 0..D-1
-#pragma unroll
-        for (int k = 0; k < HSTEPS; ++k) load_w(wreg[k]);          // steps D..D+4 -> registers
+        for (int i = 0; i < D; ++i) issue_w();                     // steps 0..D-1 -> ring slots 0..D-1
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // [P1] raw chunks 0 / 1, weights 0..D-1, gnp, add, stats visible
         asm volatile("" ::: "memory");
@@ -222,25 +215,23 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             const bool more1 = q + 1 < total_chunks;
 #pragma unroll
             for (int k = 0; k < HSTEPS; ++k) {
-                // everything but the previous step's LDS operations (ring copy: 2 writes; transform: 1 read + 2 writes in
-                // steps 0..APW-1) is complete -- LDS operations retire in order
-                if (k >= 1 && k <= APW) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-                else                    asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                // W(s+1) has landed (the consumers read it right after this barrier); of the LDS operations everything but
+                // the previous step's transform (1 read + 2 writes, steps 0..APW-1) is complete -- they retire in order
+                if (k == 1 || k == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(3)" ::"n"((D - 2) * PPW + APW) : "memory");
+                else                  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(3)" ::"n"((D - 2) * PPW) : "memory");
                 WT(WT_P_WORK)
                 __builtin_amdgcn_s_barrier();                      // step barrier (consumers: done with the previous ring slot / image)
                 asm volatile("" ::: "memory");
                 WT(WT_P_BARRIER)
-                if (k == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW) : "memory");
-                else        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPW + APW) : "memory");
-                WT(WT_P_WAITVM)
-                store_w(wreg[k]);                                  // step (q, k) + D -> ring: first read two barriers from now
+                issue_w();                                         // W(s + D) -> the slot the consumers finished two steps ago
                 if (k == 0) issue_a(min(q + 2, total_chunks - 1), q & 1);   // raw[q & 1]: chunk q was transformed during chunk q-1 (past the end: a dummy)
-                load_w(wreg[k]);                                   // the same step of the next chunk
                 static_assert(APW <= HSTEPS - 2, "the next image must be complete two steps before the chunk boundary");
+#if !(defined(WS_ABL) && WS_ABL == 3)   // ablation 3 (wrong results): no transform in the loop
                 if (more1 && k < APW) transform_slot(q + 1, k);    // chunk q+1 -> the image the consumers are NOT reading: one slot per step
+#endif
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the prefetches issued past the last step
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the refills issued past the last step
 #ifdef MIDD_CONV_TIMING
         if (tid == G::NCONS * 64) {
             wt_acc[WT_P_TOTAL] = wt_stamp() - wt_t0;
@@ -268,27 +259,70 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+    // Per tile: out = acc * 2^-(k+s) + bias (+ temb) (+ residual), NHWC 16-byte stores, per-channel sums for the next
+    // GroupNorm.  Tiles inside the image (every tile of the 2^n-sized maps) take the branch-free path: the six residual
+    // loads are requested together and the six stores issued back to back -- in the predicated form hipcc waits
+    // vmcnt(0) in every block, i.e. for the previous STORE to complete (stores count in vmcnt): six write round trips
+    // per tile, a third of the kernel in an ablation.
     auto epilogue = [&](int tile) {
         const int oy0 = (tile / a.tiles_x) * TH, ox0 = (tile % a.tiles_x) * TW;
+        const bool full = oy0 + TH <= a.OH && ox0 + TW <= a.OW;
         f32x4 tsum[NT], tsq[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int co = (ntile_wg + nt) * 16 + kq * 4;
-            const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
+        if (full) {
+            size_t o[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int pp = (wave * MT + mt) * 16 + p16;
                 const int py = pp / TW, px = pp - py * TW;
-                const int oy = oy0 + py, ox = ox0 + px;
-                if (oy < a.OH && ox < a.OW) {
-                    const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
-                    f32x4 v = acc[mt][nt] * a.out_scale + add;
-                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-                    *reinterpret_cast<f32x4*>(a.out + o) = v;
+                o[mt] = ((size_t)(b * a.OH + oy0 + py) * a.OW + ox0 + px) * a.Cout + ntile_wg * 16 + kq * 4;
+            }
+            f32x4 r[MT][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) r[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.resid != nullptr) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) r[mt][nt] = *reinterpret_cast<const f32x4*>(a.resid + o[mt] + nt * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 v = (acc[mt][nt] * a.out_scale + add) + r[mt][nt];
+                    r[mt][nt] = v;
                     tsum[nt] += v; tsq[nt] += v * v;
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(a.out + o[mt] + nt * 16) = r[mt][nt];
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int co = (ntile_wg + nt) * 16 + kq * 4;
+                const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int pp = (wave * MT + mt) * 16 + p16;
+                    const int py = pp / TW, px = pp - py * TW;
+                    const int oy = oy0 + py, ox = ox0 + px;
+                    if (oy < a.OH && ox < a.OW) {
+                        const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
+                        f32x4 v = acc[mt][nt] * a.out_scale + add;
+                        if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+                        *reinterpret_cast<f32x4*>(a.out + o) = v;
+                        tsum[nt] += v; tsq[nt] += v * v;
+                    }
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
         if (a.stat_tot != nullptr) {
@@ -348,6 +382,13 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
                 wh_n[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
                 wl_n[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
             }
+#if defined(WS_ABL) && WS_ABL == 2      // ablation (wrong results): one MFMA pass instead of three
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh_c[nt] + wl_c[nt], xh[mt] + xl[mt], acc[mt][nt], 0, 0, 0);
+#else
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -363,10 +404,13 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl_c[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+#endif
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { wh_c[nt] = wh_n[nt]; wl_c[nt] = wl_n[nt]; }
         }
+#if !(defined(WS_ABL) && WS_ABL == 4)   // ablation 4 (wrong results): no per-tile epilogue
         if ((q + 1) % nchunks == 0) { WT(WT_C_COMPUTE) epilogue(first_tile + (q / nchunks) * a.wgs_per_img); WT(WT_C_EPI) }
+#endif
     }
 #ifdef MIDD_CONV_TIMING
     if (tid == 0) {
