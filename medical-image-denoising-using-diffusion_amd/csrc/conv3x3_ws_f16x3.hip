@@ -371,7 +371,10 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
                 xl[mt] = *reinterpret_cast<const half8*>(img + frag_base[mt] + to + PLANE);
             }
             WT(WT_C_COMPUTE)
-            __builtin_amdgcn_s_barrier();       // the producers' copies from two steps ago (the next step's weights) are complete
+            // sched_barrier: hipcc otherwise sinks the next step's weight reads to their first use (one step later, with
+            // the full LDS latency in front of the MFMAs) and splits the step's MFMAs around the s_barrier
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();       // the next step's weights (DMA'd two steps ago) have landed
             asm volatile("" ::: "memory");
             WT(WT_C_BARRIER)
             const char* wslot = wring + rd_slot * WSLICE + wfrag_off;
@@ -382,6 +385,7 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
                 wh_n[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
                 wl_n[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #if defined(WS_ABL) && WS_ABL == 2      // ablation (wrong results): one MFMA pass instead of three
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -405,6 +409,7 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl_c[nt], xh[mt], acc[mt][nt], 0, 0, 0);
 #endif
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) { wh_c[nt] = wh_n[nt]; wl_c[nt] = wl_n[nt]; }
         }
