@@ -91,7 +91,6 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     }
     if (a.prologue != PRO_RAW)            // GroupNorm scale / shift of this sample, the 2^s prescale folded in (exact)
         gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
-    for (int i = tid; i < G::STAT_FLOATS; i += G::NTHREADS) stat_lds[i] = 0.f;
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
         for (int i = tid; i < G::ADD_FLOATS; i += G::NTHREADS) {
@@ -110,12 +109,13 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ntile0 = ntile_wg;
-    float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+    // per-lane sums of the output over all tiles of this persistent workgroup (see conv_mfma_f16x3.hip): folded once, at the end
+    f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     auto epilogue = [&](int tile) {
-        f32x4 tsum[NT], tsq[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int co = (ntile0 + nt) * 16 + kq * 4;
             const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
 #pragma unroll
@@ -126,22 +126,9 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
                     f32x4 v = acc[mt][nt] * a.out_scale + add;
                     if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
                     *reinterpret_cast<f32x4*>(a.out + o) = v;
-                    tsum[nt] += v; tsq[nt] += v * v;
+                    ssum[nt] += v; ssq[nt] += v * v;
                 }
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        if (a.stat_tot != nullptr) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { tsum[nt][e] = row16_sum(tsum[nt][e]); tsq[nt][e] = row16_sum(tsq[nt][e]); }
-                if (p16 == 0) {
-                    f32x4* ps = reinterpret_cast<f32x4*>(my_stat + nt * 16);
-                    f32x4* pq = reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16);
-                    *ps = *ps + tsum[nt];
-                    *pq = *pq + tsq[nt];
-                }
             }
         }
     };
@@ -209,6 +196,16 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
 
     // ---- the workgroup's per-channel sums (waves' rows folded in a fixed order) -> the tensor's totals ----
     if (a.stat_tot != nullptr) {
+        float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
+            if (p16 == 0) {
+                *reinterpret_cast<f32x4*>(my_stat + nt * 16) = ssum[nt];
+                *reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16) = ssq[nt];
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

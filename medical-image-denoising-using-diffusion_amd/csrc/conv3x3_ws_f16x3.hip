@@ -217,13 +217,21 @@ void conv3x3_ws_f16x3_kernel(const ConvArgs a) {
             for (int k = 0; k < HSTEPS; ++k) {
                 // W(s+1) has landed (the consumers read it right after this barrier); of the LDS operations everything but
                 // the previous step's transform (1 read + 2 writes, steps 0..APW-1) is complete -- they retire in order
+#if defined(WS_ABL) && WS_ABL == 5      // ablation 5 (wrong results): never wait for DMA in the loop
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+#elif defined(WS_ABL) && WS_ABL == 6    // ablation 6 (wrong results): no weight refills in the loop
+                asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+#else
                 if (k == 1 || k == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(3)" ::"n"((D - 2) * PPW + APW) : "memory");
                 else                  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(3)" ::"n"((D - 2) * PPW) : "memory");
+#endif
                 WT(WT_P_WORK)
                 __builtin_amdgcn_s_barrier();                      // step barrier (consumers: done with the previous ring slot / image)
                 asm volatile("" ::: "memory");
                 WT(WT_P_BARRIER)
+#if !(defined(WS_ABL) && WS_ABL == 6)
                 issue_w();                                         // W(s + D) -> the slot the consumers finished two steps ago
+#endif
                 if (k == 0) issue_a(min(q + 2, total_chunks - 1), q & 1);   // raw[q & 1]: chunk q was transformed during chunk q-1 (past the end: a dummy)
                 static_assert(APW <= HSTEPS - 2, "the next image must be complete two steps before the chunk boundary");
 #if !(defined(WS_ABL) && WS_ABL == 3)   // ablation 3 (wrong results): no transform in the loop

@@ -109,7 +109,8 @@ template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
 #endif
 // the register budget is capped so that as many workgroups as the LDS target allows are resident
 // (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4) ? MIDD_CONV16_WAVES_PER_SIMD : 1)
+// (stride-2 tiles stage a 33x17 halo: their LDS allows one workgroup per CU anyway, so they get the whole register file)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && STRIDE == 1) ? MIDD_CONV16_WAVES_PER_SIMD : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
@@ -233,7 +234,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             if (g_off[s] > -2) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(raw + slot * 16);
                 v = v * sc + sh;
+#if defined(C16_ABL) && C16_ABL == 4     // ablation 4 (wrong results): no SiLU
+                if (false) {
+#else
                 if (a.prologue == PRO_GN_SILU) {
+#endif
 #pragma unroll
                     for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
                         v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
@@ -288,9 +293,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     issue_a(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
+#if !(defined(C16_ABL) && C16_ABL == 6)  // ablation 6 (wrong results): no GroupNorm prologue
     if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
         gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
-    for (int i = tid; i < G::STAT_FLOATS; i += NTHREADS) stat_lds[i] = 0.f;
+#endif
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
         for (int i = tid; i < G::ADD_FLOATS; i += NTHREADS) {
@@ -330,6 +336,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+#if !(defined(C16_ABL) && C16_ABL == 8)  // ablation 8 (wrong results): one MFMA pass instead of three
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -340,6 +347,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], xh[mt], acc[mt][nt], 0, 0, 0);
+#endif
     };
 
     // The activation fragments of a step only depend on the chunk's image (published at the chunk
@@ -378,12 +386,16 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // GroupNorm partial sums of the output run across ALL tiles of this (persistent) workgroup and are
     // published once at the end: one row per (workgroup, wave) instead of one per (tile, wave).  Per tile the
     // 16 pixel lanes are folded (fixed order -> deterministic) and lanes p16 == 0 add into the wave's LDS row.
-    float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+    // GroupNorm partial sums of the output: each lane keeps the sums of ITS pixels (fixed (pixel lane, cout quad) of every
+    // tile it walks) in registers across all tiles of this persistent workgroup; the 16 pixel lanes are folded (DPP row
+    // sums, fixed order) and the waves combined through LDS ONCE, at the end.  (Doing the DPP fold and an LDS
+    // read-modify-write per tile cost 9 % of the whole sampler: ablation with the statistics removed.)
+    f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     auto epilogue = [&]() {
-        f32x4 tsum[NT], tsq[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            tsum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tsq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int co = (ntile0 + nt) * 16 + kq * 4;
             const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
 #pragma unroll
@@ -396,22 +408,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     f32x4 v = acc[mt][nt] * a.out_scale + add;
                     if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
                     *reinterpret_cast<f32x4*>(a.out + o) = v;
-                    tsum[nt] += v; tsq[nt] += v * v;
+                    ssum[nt] += v; ssq[nt] += v * v;
                 }
                 acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        if (a.stat_tot != nullptr) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { tsum[nt][e] = row16_sum(tsum[nt][e]); tsq[nt][e] = row16_sum(tsq[nt][e]); }
-                if (p16 == 0) {
-                    f32x4* ps = reinterpret_cast<f32x4*>(my_stat + nt * 16);
-                    f32x4* pq = reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16);
-                    *ps = *ps + tsum[nt];
-                    *pq = *pq + tsq[nt];
-                }
             }
         }
     };
@@ -419,6 +418,16 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // the tensor's totals with exact integer atomics (stats_common.h)
     auto publish_stats = [&]() {
         if (a.stat_tot == nullptr) return;
+        float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
+            if (p16 == 0) {
+                *reinterpret_cast<f32x4*>(my_stat + nt * 16) = ssum[nt];
+                *reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16) = ssq[nt];
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -430,7 +439,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
             const int ch = (ntile_wg + wn_i * NT) * 16 + c;
+#if defined(C16_ABL) && C16_ABL == 7     // ablation 7 (wrong results): plain store instead of the atomics
+            *reinterpret_cast<float*>(stat_slot(a.stat_tot, b, a.Cout, ch, a.stat_rep, 0, which)) = t;
+#else
             stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ch, a.stat_rep, (blockIdx.x - b * a.wgs_per_img) % a.stat_rep, which), t);
+#endif
         }
     };
 
@@ -490,7 +503,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     ts_after_epi = true;
 #endif
                 }
+#if !(defined(C16_ABL) && C16_ABL == 5)  // ablation 5 (wrong results): no transform in the loop
                 transform(next_chunk);
+#endif
                 TS(TS_TRANSFORM)
                 if constexpr (WM == 1) {        // steps have no barrier of their own: publish the new image here
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -656,7 +671,10 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
 
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
-    if (conv3x3_ws_tile_ok(t, a.C0, a.C1, a.Cout) && a.H == a.OH && a.W == a.OW) return conv3x3_ws_launch(a, s);
+    static const long ws_max_hw = getenv("MIDD_WS_MAX_HW") ? atol(getenv("MIDD_WS_MAX_HW")) : (1L << 40);
+    static const long ws_min_hw = getenv("MIDD_WS_MIN_HW") ? atol(getenv("MIDD_WS_MIN_HW")) : 0;
+    if (conv3x3_ws_tile_ok(t, a.C0, a.C1, a.Cout) && a.H == a.OH && a.W == a.OW && (long)a.H * a.W <= ws_max_hw && (long)a.H * a.W >= ws_min_hw)
+        return conv3x3_ws_launch(a, s);
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
         if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \

@@ -1,6 +1,8 @@
 #!/bin/bash
-# Ablation builds of the WS kernel (wrong results, timing only): unsplit bench value per library
-for L in medical-image-denoising-using-diffusion_amd/libmidd.so libmidd_abl1.so libmidd_abl2.so libmidd_abl3.so libmidd_abl4.so; do
-  v=$(MIDD_SPLIT=1 MIDD_LIBRARY=$PWD/$L timeout -k 10 300 python bench.py --steps 3 --warmup 1 --cpu-iters 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=[x for x in d['kernels'] if 'ws' in x['name']]; print('%.2f img/s  ws kernel %.1f ms' % (d['value'], k[0]['ms'] if k else -1))" 2>&1 | tail -1)
-  echo "$L: $v"
+# Ablation builds (wrong results, timing only): bench value per library, default split and unsplit
+for L in "$@"; do
+  for SP in 2 1; do
+    v=$(MIDD_WS=0 MIDD_SPLIT=$SP MIDD_LIBRARY=$PWD/$L timeout -k 10 300 python bench.py --steps 3 --warmup 1 --cpu-iters 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.2f img/s' % d['value'])" 2>&1 | tail -1)
+    echo "$L split=$SP: $v"
+  done
 done
