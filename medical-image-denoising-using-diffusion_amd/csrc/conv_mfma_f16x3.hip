@@ -671,10 +671,6 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
 
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
-    static const long ws_max_hw = getenv("MIDD_WS_MAX_HW") ? atol(getenv("MIDD_WS_MAX_HW")) : (1L << 40);
-    static const long ws_min_hw = getenv("MIDD_WS_MIN_HW") ? atol(getenv("MIDD_WS_MIN_HW")) : 0;
-    if (conv3x3_ws_tile_ok(t, a.C0, a.C1, a.Cout) && a.H == a.OH && a.W == a.OW && (long)a.H * a.W <= ws_max_hw && (long)a.H * a.W >= ws_min_hw)
-        return conv3x3_ws_launch(a, s);
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
         if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \

@@ -788,8 +788,6 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
                 snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d>", o.tile.mt, o.tile.nt);
-            else if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && conv3x3_ws_tile_ok(o.tile, o.s0.C, o.has_s1 ? o.s1.C : 0, o.dst.C))
-                snprintf(buf, sizeof(buf), "midd::conv3x3_ws_f16x3_kernel");
             else
                 snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
                          p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,

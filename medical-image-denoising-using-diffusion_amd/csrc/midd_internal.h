@@ -60,9 +60,6 @@ int conv16_wgs_per_img(int tiles, int B, int ny, int target = 0);   // target 0:
 bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t);   // ConvTile::tw == 0 marks it
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);      // persistent workgroups per sample (f16x3 kernels)
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
-// wave-specialised 3x3 stride-1 kernel (conv3x3_ws_f16x3.hip): used by conv16_launch where the tile is 16x8 px x 48 couts
-bool conv3x3_ws_tile_ok(const ConvTile& t, int C0, int C1, int Cout);
-hipError_t conv3x3_ws_launch(const ConvArgs& a, hipStream_t s);
 // 16-channel blocks staged per K chunk of the f16x3 kernel (shared with the host packer).
 //   3x3: 1 -> 16 channels per chunk, two taps per MFMA step (10 % padded MFMA slots, but half the
 //             activation LDS of a 32-channel chunk, i.e. three resident workgroups per CU)
