@@ -25,7 +25,8 @@ struct Conv1Geom {
     static constexpr int WSTEP = NT * 2048;                  // bytes of one K-step's weights (hi + lo, NT cout tiles)
     static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
     static constexpr int ADD_FLOATS = NT * 16;
-    static int lds_bytes(int cin) { return ((cin + 31) / 32) * WSTEP + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
+    static int weight_bytes(int cin) { const int w = ((cin + 31) / 32) * WSTEP; return w < 4096 ? 4096 : w; }      // also the statistics scratch at the end
+    static int lds_bytes(int cin) { return weight_bytes(cin) + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
 };
 
 template <int MT, int NT>
@@ -52,7 +53,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     const int ntile_wg = blockIdx.y * NT;
 
     char* const wl = lds;                                                        // [step][NT][hi|lo][lane] x 16 B
-    float* const stat_lds = reinterpret_cast<float*>(wl + nsteps * WSTEP);       // [wave][2][NT*16]
+    float* const stat_lds = reinterpret_cast<float*>(wl + max(nsteps * WSTEP, 4096));       // [wave][2][NT*16]  (Conv1Geom::weight_bytes)
     float* const add_lds = stat_lds + G::STAT_FLOATS;                            // [NT*16]
     float* const gnp = add_lds + G::ADD_FLOATS;                                  // [2][Cin] scale, shift
 
@@ -90,7 +91,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         }
     }
     if (a.prologue != PRO_RAW)            // GroupNorm scale / shift of this sample, the 2^s prescale folded in (exact)
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
         for (int i = tid; i < G::ADD_FLOATS; i += G::NTHREADS) {
@@ -210,13 +211,18 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         constexpr int ROWF = 2 * NT * 16;
+        float* const vals = reinterpret_cast<float*>(wl);              // [2][NT*16]; the weight image is idle now
         for (int i = tid; i < ROWF; i += G::NTHREADS) {
-            const int which = i / (NT * 16), c = i - which * (NT * 16);
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
-            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ntile_wg * 16 + c, a.stat_rep, first_tile % a.stat_rep, which), t);
+            vals[i] = t;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stat_publish_cols(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, first_tile % a.stat_rep, ntile_wg * 16, NT * 16,
+                          vals, reinterpret_cast<stat_word*>(wl + 512), tid, G::NTHREADS);      // <= 49 blocks x 48 B behind the values
     }
 }
 

@@ -295,7 +295,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     for (int i = 0; i < D; ++i) issue_w();
 #if !(defined(C16_ABL) && C16_ABL == 6)  // ablation 6 (wrong results): no GroupNorm prologue
     if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, 1.0f, gnp, tid, NTHREADS);
 #endif
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
@@ -432,19 +432,22 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         constexpr int ROWF = 2 * NT * 16;                              // floats of one wave's row
-        for (int i = tid; i < WN * ROWF; i += NTHREADS) {
-            const int wn_i = i / ROWF, r = i - wn_i * ROWF;
-            const int which = r / (NT * 16), c = r - which * (NT * 16);
+        constexpr int NCOL = WN * NT * 16;                             // channels of this workgroup's slice
+        float* const vals = reinterpret_cast<float*>(raw);             // [2][NCOL]; the staging buffers are idle now
+        for (int i = tid; i < 2 * NCOL; i += NTHREADS) {
+            const int which = i / NCOL, col = i - which * NCOL;
+            const int wn_i = col / (NT * 16), c = col - wn_i * (NT * 16);
             float t = 0.f;
 #pragma unroll
-            for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + r];
-            const int ch = (ntile_wg + wn_i * NT) * 16 + c;
-#if defined(C16_ABL) && C16_ABL == 7     // ablation 7 (wrong results): plain store instead of the atomics
-            *reinterpret_cast<float*>(stat_slot(a.stat_tot, b, a.Cout, ch, a.stat_rep, 0, which)) = t;
-#else
-            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, ch, a.stat_rep, (blockIdx.x - b * a.wgs_per_img) % a.stat_rep, which), t);
-#endif
+            for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + which * (NT * 16) + c];
+            vals[i] = t;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        static_assert(G::RAW_BYTES + G::IMG_BYTES + RING * WSLICE >= 2 * NCOL * 4 + 64 + (NTHREADS / 2 + 1) * STAT_WORDS * 8, "statistics scratch (raw buffer, image, weight ring: all idle here)");
+        stat_publish_cols(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, (blockIdx.x - b * a.wgs_per_img) % a.stat_rep, ntile_wg * 16, NCOL,
+                          vals, reinterpret_cast<stat_word*>(raw + ((2 * NCOL * 4 + 63) & ~63)), tid, NTHREADS);
     };
 
     // ---- tile / chunk loop -----------------------------------------------------------------------

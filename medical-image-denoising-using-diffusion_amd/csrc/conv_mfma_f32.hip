@@ -50,6 +50,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
 
     __shared__ f32x4 lds[2][NSLOT];
     __shared__ float fold_scratch[WM * WN * 2 * NT * 16];  // statistics: one row per wave
+    __shared__ stat_word stat_acc[(NTHREADS / 2 + 1) * STAT_WORDS];      // ... and the publish step's block accumulators
     extern __shared__ float gnp[];                         // [2][Cin] GroupNorm scale, shift of this sample
 
     const int tid = threadIdx.x;
@@ -151,7 +152,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
     for (int nt = 0; nt < NT; ++nt) wcur[nt] = wp[nt * 64];
 
     if (a.prologue != PRO_RAW) {
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_tot1, a.C1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_hw, b, 1.0f, gnp, tid, NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, 1.0f, gnp, tid, NTHREADS);
         __syncthreads();
     }
     stage_load(0);
@@ -237,15 +238,19 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
             }
         }
         __syncthreads();
-        const int c0 = blockIdx.y * (WN * NT * 16);
-        for (int i = tid; i < WN * ROWF; i += NTHREADS) {
-            const int wn_i = i / ROWF, r = i - wn_i * ROWF;
-            const int which = r / (NT * 16), c = r - which * (NT * 16);
+        constexpr int NCOL = WN * NT * 16;
+        float* const vals = reinterpret_cast<float*>(&lds[0][0]);            // [2][NCOL]; the staging buffers are idle now
+        for (int i = tid; i < 2 * NCOL; i += NTHREADS) {
+            const int which = i / NCOL, col = i - which * NCOL;
+            const int wn_i = col / (NT * 16), c = col - wn_i * (NT * 16);
             float t = 0.f;
 #pragma unroll
-            for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + r];
-            stat_atomic_add(stat_slot(a.stat_tot, b, a.Cout, c0 + wn_i * NT * 16 + c, a.stat_rep, trem % a.stat_rep, which), t);
+            for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + which * (NT * 16) + c];
+            vals[i] = t;
         }
+        __syncthreads();
+        static_assert(sizeof(lds) >= 2 * NCOL * 4, "statistics scratch");
+        stat_publish_cols(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, trem % a.stat_rep, blockIdx.y * NCOL, NCOL, vals, stat_acc, tid, NTHREADS);
     }
 }
 

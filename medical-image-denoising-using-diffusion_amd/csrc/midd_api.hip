@@ -58,7 +58,7 @@ struct HostWeight { std::vector<int64_t> shape; std::vector<float> data; bool lo
 struct TensorRef {
     size_t off = 0; int C = 0, H = 0, W = 0;
     // GroupNorm statistics, if produced: per-channel fixed-point totals [B][C][replica][2][3] (stats_common.h), inside the statistics arena
-    size_t tot_off = (size_t)-1;
+    size_t tot_off = (size_t)-1; int stat_id = -1, stat_bs = 0;      // stat_id: index into the builder's table until the arena is placed
 };
 
 struct GnRef { size_t gamma = 0, beta = 0; bool on = false; };        // affine of the GroupNorm in front of a consumer
@@ -571,15 +571,23 @@ struct Builder {
         t.off = bump.take((size_t)B * H * W * C * sizeof(float));
         return t;
     }
-    // totals live in one arena (offsets relative to it until build_program places it) so ONE memset clears them all
-    size_t stats_cur = 0;
-    void alloc_stats(TensorRef& t) {
-        t.tot_off = stats_cur;
-        stats_cur += ((size_t)B * t.C * g->stat_rep * STAT_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
+    // Totals live in one arena so ONE memset clears them all.  A tensor's totals are kept per block of `bs` channels: the
+    // largest size every consuming GroupNorm's groups are whole multiples of (consumers register with gn_consumer).
+    struct StatInfo { int C, bs; size_t off; };
+    std::vector<StatInfo> stats;
+    static int gcd(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+    void alloc_stats(TensorRef& t) { t.stat_id = (int)stats.size(); stats.push_back(StatInfo{t.C, t.C, 0}); }
+    // GroupNorm(8, C0 + C1) over (s0 [, s1]): group boundaries lie at multiples of cg from the start of s0
+    int gn_consumer(const TensorRef& s0, const TensorRef* s1) {
+        if (s0.stat_id < 0 || (s1 && s1->stat_id < 0)) return fail(MI_EINVAL, "internal: GroupNorm input without statistics");
+        const int cg = (s0.C + (s1 ? s1->C : 0)) / GN_GROUPS_;
+        stats[s0.stat_id].bs = gcd(stats[s0.stat_id].bs, cg);
+        if (s1) stats[s1->stat_id].bs = gcd(gcd(stats[s1->stat_id].bs, cg), s0.C % cg);      // gcd(x, 0) == x
+        return MI_OK;
     }
     // per-channel totals for a tensor no MFMA convolution produced
     void ensure_stats(TensorRef& t) {
-        if (t.tot_off != (size_t)-1) return;
+        if (t.stat_id >= 0) return;
         alloc_stats(t);
         Op o{}; o.kind = OP_CHAN_TOT; o.s0 = t; o.stat_rows = chan_partial_rows(t.H * t.W, t.C); g->ops.push_back(o);
     }
@@ -589,8 +597,7 @@ struct Builder {
         // wscale = 2^-k / 2^s undoes the weight and the activation prescale; raw operands are not prescaled
         o.out_scale = (prologue == PRO_RAW && p->cfg.compute_mode == MI_COMPUTE_F16X3) ? wscale * ACT_PRESCALE_H : wscale;
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col; o.gn = gn;
-        if (gn.on && (s0.tot_off == (size_t)-1 || (s1 && s1->tot_off == (size_t)-1)))
-            return fail(MI_EINVAL, "internal: GroupNorm input without statistics");
+        if (gn.on) { if (int rcg = gn_consumer(s0, s1)) return rcg; }
         if (resid) { o.resid = *resid; o.has_resid = true; }
         const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
                             ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
@@ -714,15 +721,21 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     }
     if ((rc = flush_up())) return rc;
     if (h.H != H || h.W != W) return fail(MI_EINVAL, "network output is %dx%d for a %dx%d input", h.H, h.W, H, W);
-    if (h.tot_off == (size_t)-1) return fail(MI_EINVAL, "internal: network output without statistics");
+    if ((rc = bld.gn_consumer(h, nullptr))) return rc;
     { Op o{}; o.kind = OP_OUT; o.s0 = h; o.gn = GnRef{p->g_out, p->be_out, true}; g->ops.push_back(o); }
-    // place the statistics arena and make the tensors' offsets absolute
-    g->stats_bytes = bld.stats_cur;
+    // every consumer is known: size the totals blocks, place the statistics arena, resolve the tensors' references
+    size_t cur = 0;
+    for (auto& st : bld.stats) {
+        st.off = cur;
+        cur += ((size_t)B * (st.C / st.bs) * g->stat_rep * STAT_WORDS * sizeof(stat_word) + 255) & ~(size_t)255;
+    }
+    g->stats_bytes = cur;
     g->stats_off = bld.bump.take(g->stats_bytes);
-    for (Op& o : g->ops)
-        for (TensorRef* t : {&o.s0, &o.s1, &o.dst, &o.resid})
-            if (t->tot_off != (size_t)-1) t->tot_off += g->stats_off;
-    for (auto& kv : g->outputs) if (kv.second.tot_off != (size_t)-1) kv.second.tot_off += g->stats_off;
+    auto resolve = [&](TensorRef& t) {
+        if (t.stat_id >= 0) { t.tot_off = g->stats_off + bld.stats[t.stat_id].off; t.stat_bs = bld.stats[t.stat_id].bs; }
+    };
+    for (Op& o : g->ops) for (TensorRef* t : {&o.s0, &o.s1, &o.dst, &o.resid}) resolve(*t);
+    for (auto& kv : g->outputs) resolve(kv.second);
     g->bytes = (bld.bump.cur + 255) & ~(size_t)255;
     return MI_OK;
 }
@@ -848,7 +861,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                                    g->H, g->W, o.dst.C, s);
                 break;
             case OP_CHAN_TOT:
-                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), g->stat_rep, B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
+                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), g->stat_rep, o.s0.stat_bs, B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
                 break;
             case OP_CONV: {
                 ConvArgs a{};
@@ -858,13 +871,15 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue; a.stat_rep = g->stat_rep;
                 if (o.gn.on) {
-                    a.gn_tot0 = T(o.s0.tot_off); a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : nullptr;
-                    a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f; a.gn_hw = o.s0.H * o.s0.W;
+                    a.gn_tot0 = T(o.s0.tot_off); a.gn_bs0 = o.s0.stat_bs;
+                    a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : T(o.s0.tot_off); a.gn_bs1 = o.has_s1 ? o.s1.stat_bs : 1;
+                    a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
+                    a.gn_inv_n = 1.0 / ((double)o.s0.H * o.s0.W * ((a.C0 + a.C1) / GN_GROUPS_));
                 }
                 if (o.temb_col >= 0) { a.temb = p->ttab + o.temb_col; a.temb_stride = p->temb_cols; a.trow = reinterpret_cast<const int*>(ws + g->trow_off); }
                 a.resid = o.has_resid ? F(o.resid.off) : nullptr;
                 a.out = F(o.dst.off); a.out_scale = o.out_scale;
-                if (o.want_stats) a.stat_tot = T(o.dst.tot_off);
+                if (o.want_stats) { a.stat_tot = T(o.dst.tot_off); a.stat_bs = o.dst.stat_bs; }
                 a.persist_wgs = g->persist_wgs;
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3) ? conv16_launch(a, o.tile, s) : conv_launch(a, o.tile, s);
                 break;
@@ -882,7 +897,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 break;
             case OP_OUT: {
                 OutConvArgs a{};
-                a.src = F(o.s0.off); a.gn_tot = T(o.s0.tot_off); a.stat_rep = g->stat_rep; a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
+                a.src = F(o.s0.off); a.gn_tot = T(o.s0.tot_off); a.stat_rep = g->stat_rep; a.gn_bs = o.s0.stat_bs; a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                 a.w = wd + p->w_out; a.bias = wd + p->b_out;
                 a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
                 a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;

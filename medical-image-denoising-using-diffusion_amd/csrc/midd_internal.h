@@ -21,10 +21,11 @@ struct ConvArgs {
     const float* bias;      // [Cout]
     int Cout;
     // GroupNorm of the INPUT (prologue != RAW): per-channel fixed-point (sum, sum of squares) totals of the two
-    // concatenated sources, [B][C0][replica][2][3] / [B][C1][replica][2][3] limbs, accumulated by the producers (stats_common.h); every
+    // concatenated sources, [B][C0/bs0][rep][2][3] / [B][C1/bs1][rep][2][3] limbs, accumulated by the producers (stats_common.h); every
     // workgroup derives scale = rstd*gamma, shift = beta - mean*rstd*gamma of its sample in its prologue
     const stat_word* gn_tot0; const stat_word* gn_tot1;
-    const float* gn_gamma; const float* gn_beta; float gn_eps; int gn_hw;      // affine [Cin], eps, pixels per channel
+    int gn_bs0, gn_bs1;     // channels per totals block of each source (whole blocks per GroupNorm group)
+    const float* gn_gamma; const float* gn_beta; float gn_eps; double gn_inv_n;      // affine [Cin], eps, 1 / (pixels * channels per group)
     int prologue;
     const float* temb;      // time table [rows][temb_stride], already offset to this block's column
     int temb_stride;
@@ -33,9 +34,10 @@ struct ConvArgs {
     float* out;             // NHWC [B][OH][OW][Cout]
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
-    // the pixels it produced to the totals [B][Cout][replica][2][3] (exact integer atomics, stats_common.h); zeroed per forward
+    // the pixels it produced to the totals [B][Cout/bs][rep][2][3] (exact integer atomics, stats_common.h); zeroed per forward
     stat_word* stat_tot;
-    int stat_rep;           // copies per channel of every totals block of this program (stats_common.h), also for gn_tot0/1
+    int stat_rep;           // copies of every totals block of this program (stats_common.h), also for gn_tot0/1
+    int stat_bs;            // channels per totals block of the OUTPUT
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
     int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default)
@@ -77,8 +79,8 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
 // ---------------------------------------------------------------- GroupNorm statistics (stats_common.h)
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
 // per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
-// sample each add their partial sums to tot [B][C][replica][2][3]
-hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int B, int HW, int C, int rows, hipStream_t s);
+// sample each add their partial sums to tot [B][C/bs][rep][2][3]
+hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
 // ---------------------------------------------------------------- pre/post-processing (prepost.hip)
@@ -104,7 +106,7 @@ hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9
 
 struct OutConvArgs {
     const float* src;       // NHWC [B][H][W][C]
-    const stat_word* gn_tot; int stat_rep; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C][replica][2][3], affine [C]
+    const stat_word* gn_tot; int stat_rep, gn_bs; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C/bs][rep][2][3], affine [C]
     const float* w;         // [ic][9][C]
     const float* bias;      // [ic]
     int B, H, W, C, ic;

@@ -97,7 +97,7 @@ void out_conv_kernel(const OutConvArgs a) {
     const int C = a.C;
     for (int i = tid; i < a.ic * 9 * C; i += 256) wl[i] = a.w[i];
     // (second source: C1 = 0, never read; a literal nullptr there crashes hipcc 7.2's inliner)
-    gn_prologue_lds(a.gn_tot, C, a.gn_tot, 0, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.H * a.W, b, 1.0f, gnp, tid, 256);
+    gn_prologue_lds(a.gn_tot, C, a.gn_bs, a.gn_tot, 0, 1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, 1.0 / ((double)a.H * a.W * (C / GN_GROUPS_C)), b, 1.0f, gnp, tid, 256);
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};          // ic <= 4 output channels
     for (int c0 = 0; c0 < C; c0 += 16) {
