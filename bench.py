@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--inference-steps", type=int, default=50)
     ap.add_argument("--noise-steps", type=int, default=50)
     ap.add_argument("--cpu-iters", type=int, default=5, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--latency-reps", type=int, default=3,
+                    help="single-image latency leg after the timed region (0 = skip: profile runs, so that rocprofv3's "
+                         "per-kernel averages cover the bench workload only)")
     ap.add_argument("--compute", default=None, choices=["f16x3", "f32"],
                     help="MFMA arithmetic: split-fp16 x3 (default) or fp32-input MFMA")
     args = ap.parse_args()
@@ -248,16 +251,16 @@ def main():
             key=lambda d: -d["ms"])[:24]
 
         # ---- CPU baseline (rank 0, N = 1 only) + a parity spot check on the same sample ----
-        if world == 1:
+        if world == 1 and args.latency_reps > 0:
             # serving regime (run.py:107 denoises one image per request): latency of a single image
             one = torch.from_numpy(synthetic_xray(1, S, S, seed=1234)).to(dev)
             den.denoise(one, inference_steps=args.inference_steps)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(args.latency_reps):
                 den.denoise(one, inference_steps=args.inference_steps)
             torch.cuda.synchronize()
-            result["latency_batch1"] = {"ms_per_image": 1e3 * (time.perf_counter() - t1) / 3, "iterations": n_iters, "image": [S, S]}
+            result["latency_batch1"] = {"ms_per_image": 1e3 * (time.perf_counter() - t1) / args.latency_reps, "iterations": n_iters, "image": [S, S]}
         if world == 1 and args.cpu_iters > 0 and S <= 512:
             x_cpu, steps, base = cpu_baseline(sd_np, cfg, S, args.noise_steps, args.cpu_iters, Bp)
             result["cpu_baseline"] = base

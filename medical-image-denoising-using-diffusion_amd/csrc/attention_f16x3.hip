@@ -363,9 +363,9 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
     hipLaunchKernelGGL(attention_prep_kernel, dim3(Npad / 32, heads, B), dim3(256), 0, s, qkv, Kp, Vp, N, Npad, C, D, heads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // split the keys until ~512 workgroups exist (two per CU), keeping at least two 32-key tiles per split
+    // split the keys until 256 workgroups exist (one per CU; a 512 target measured slower), keeping at least two 32-key tiles per split
     const int qblocks = (N + A16_QB - 1) / A16_QB, tiles = (N + A16_KT - 1) / A16_KT;
-    static const int want_wgs = getenv("MIDD_ATT_WGS") ? atoi(getenv("MIDD_ATT_WGS")) : 256;
+    constexpr int want_wgs = 256;
     int ksplit = 1;
     while ((long)qblocks * heads * B * ksplit < want_wgs && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
     const int tps = (tiles + ksplit - 1) / ksplit;

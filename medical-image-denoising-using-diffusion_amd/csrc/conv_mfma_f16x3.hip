@@ -664,6 +664,8 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
         // enough workgroups first; then the pixels one weight fetch is shared over (the weight stream from L2 is what
         // starves small tiles), then the couts one activation staging is shared over
         const long share = (long)bm * 8 + d.wn;
+        // (forcing the 2x2-wave 96-cout tile on the <= 32x32 / <= 64x64 maps -- the GroupNorm / SiLU / split transform shared by
+        // two cout slices -- measured -6.5 % / -7 %: its 12 KB weight slices leave a two-slot ring, one step in flight)
         const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
         if (score > best_score) { best_score = score; best = &d; }
     }
