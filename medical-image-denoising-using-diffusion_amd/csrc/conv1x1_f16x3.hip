@@ -202,27 +202,24 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
-            if (p16 == 0) {
-                *reinterpret_cast<f32x4*>(my_stat + nt * 16) = ssum[nt];
-                *reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16) = ssq[nt];
+            if (p16 == 0) {                     // raw stores: see stat_publish
+                lds_store_raw(my_stat + nt * 16, ssum[nt]);
+                lds_store_raw(my_stat + NT * 16 + nt * 16, ssq[nt]);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
         constexpr int ROWF = 2 * NT * 16;
-        float* const vals = reinterpret_cast<float*>(wl);              // [2][NT*16]; the weight image is idle now
-        for (int i = tid; i < ROWF; i += G::NTHREADS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the K loop has no barrier: every wave must be done reading the
+        __builtin_amdgcn_s_barrier();                              // weight image before the block accumulators go there
+        asm volatile("" ::: "memory");
+        // the waves' rows are folded in a fixed order inside stat_publish
+        auto fold = [&](int i) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < G::NW; ++m) t += stat_lds[m * ROWF + i];
-            vals[i] = t;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stat_publish_cols(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, first_tile % a.stat_rep, ntile_wg * 16, NT * 16,
-                          vals, reinterpret_cast<stat_word*>(wl + 512), tid, G::NTHREADS);      // <= 49 blocks x 48 B behind the values
+            return t;
+        };
+        stat_publish(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, first_tile % a.stat_rep, ntile_wg * 16, NT * 16,
+                     fold, reinterpret_cast<stat_word*>(wl), tid, G::NTHREADS);      // <= 50 blocks x 48 B in the idle weight image
     }
 }
 

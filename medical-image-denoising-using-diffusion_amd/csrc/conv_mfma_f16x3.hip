@@ -293,6 +293,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     issue_a(0);
 #pragma unroll
     for (int i = 0; i < D; ++i) issue_w();
+    // (Measured in round 2: requesting the totals BEFORE the DMAs through loads the compiler does not track, with a counted
+    // wait, so that the GroupNorm arithmetic overlaps the DMA latency instead of following it -- 0 % split, -0.7 % unsplit.)
 #if !(defined(C16_ABL) && C16_ABL == 6)  // ablation 6 (wrong results): no GroupNorm prologue
     if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
         gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, 1.0f, gnp, tid, NTHREADS);
@@ -394,60 +396,78 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     auto epilogue = [&]() {
+        // The residual operand comes through loads the compiler does not track, one 16-pixel row (NT loads) at a time, awaited
+        // once: a tracked load is awaited with vmcnt(0) while LDS-DMA traffic is pending (stats_common.h), and -- vmcnt counting
+        // stores too -- that also waits for the PREVIOUS block's output store to retire: MT*NT - 1 serialised store round
+        // trips per tile instead of MT - 1.  (All MT*NT loads at once need 12 more registers than the kernel has.)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = (ntile0 + nt) * 16 + kq * 4;
-            const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pp = (wm * MT + mt) * 16 + p16;
+            const int py = pp / TW, px = pp - py * TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            if (oy < a.OH && ox < a.OW) {
+                const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + ntile0 * 16 + kq * 4;
+                f32x4 rres[NT];
+                if (a.resid != nullptr) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int pp = (wm * MT + mt) * 16 + p16;
-                const int py = pp / TW, px = pp - py * TW;
-                const int oy = oy0 + py, ox = ox0 + px;
-                if (oy < a.OH && ox < a.OW) {
-                    const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + co;
-                    f32x4 v = acc[mt][nt] * a.out_scale + add;
-                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-                    *reinterpret_cast<f32x4*>(a.out + o) = v;
-                    ssum[nt] += v; ssq[nt] += v * v;
+                    for (int nt = 0; nt < NT; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[nt]) : "v"(a.resid + o + nt * 16) : "memory");
+                    if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]), "+v"(rres[1]), "+v"(rres[2]) :: "memory");
+                    else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]), "+v"(rres[1]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]) :: "memory");
                 }
-                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
+                    f32x4 v = acc[mt][nt] * a.out_scale + add;
+                    if (a.resid != nullptr) v += rres[nt];
+                    *reinterpret_cast<f32x4*>(a.out + o + nt * 16) = v;
+#if !(defined(C16_ABL) && C16_ABL == 1)  // ablation 1 (wrong results): no statistics of the output
+                    ssum[nt] += v; ssq[nt] += v * v;
+#endif
+                }
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     // the waves' LDS rows are folded over wm in a fixed order after a barrier; the workgroup's per-channel sums go to
     // the tensor's totals with exact integer atomics (stats_common.h)
     auto publish_stats = [&]() {
         if (a.stat_tot == nullptr) return;
+#if defined(C16_ABL) && C16_ABL == 1
+        return;
+#endif
         float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { ssum[nt][e] = row16_sum(ssum[nt][e]); ssq[nt][e] = row16_sum(ssq[nt][e]); }
-            if (p16 == 0) {
-                *reinterpret_cast<f32x4*>(my_stat + nt * 16) = ssum[nt];
-                *reinterpret_cast<f32x4*>(my_stat + NT * 16 + nt * 16) = ssq[nt];
+            if (p16 == 0) {                     // raw stores: see stat_publish
+                lds_store_raw(my_stat + nt * 16, ssum[nt]);
+                lds_store_raw(my_stat + NT * 16 + nt * 16, ssq[nt]);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
         constexpr int ROWF = 2 * NT * 16;                              // floats of one wave's row
         constexpr int NCOL = WN * NT * 16;                             // channels of this workgroup's slice
-        float* const vals = reinterpret_cast<float*>(raw);             // [2][NCOL]; the staging buffers are idle now
-        for (int i = tid; i < 2 * NCOL; i += NTHREADS) {
+        // the waves' rows are folded over wm in a fixed order inside stat_publish (its first barrier publishes them)
+        auto fold = [&](int i) {
             const int which = i / NCOL, col = i - which * NCOL;
             const int wn_i = col / (NT * 16), c = col - wn_i * (NT * 16);
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += stat_lds[(m * WN + wn_i) * ROWF + which * (NT * 16) + c];
-            vals[i] = t;
+            return t;
+        };
+        static_assert(G::RAW_BYTES + G::IMG_BYTES + RING * WSLICE >= (NCOL + 2) * STAT_WORDS * 8, "block accumulators in the staging buffers (raw, image, ring: contiguous, idle here)");
+        // the landing buffer has been idle for every wave since the last transform; the image / ring behind it may still be
+        // read by a wave in its last steps, so accumulators that spill into them wait for everybody first
+        if constexpr (G::RAW_BYTES < (NCOL + 2) * STAT_WORDS * 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        static_assert(G::RAW_BYTES + G::IMG_BYTES + RING * WSLICE >= 2 * NCOL * 4 + 64 + (NTHREADS / 2 + 1) * STAT_WORDS * 8, "statistics scratch (raw buffer, image, weight ring: all idle here)");
-        stat_publish_cols(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, (blockIdx.x - b * a.wgs_per_img) % a.stat_rep, ntile_wg * 16, NCOL,
-                          vals, reinterpret_cast<stat_word*>(raw + ((2 * NCOL * 4 + 63) & ~63)), tid, NTHREADS);
+        stat_publish(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, (blockIdx.x - b * a.wgs_per_img) % a.stat_rep, ntile_wg * 16, NCOL,
+                     fold, reinterpret_cast<stat_word*>(raw), tid, NTHREADS);
     };
 
     // ---- tile / chunk loop -----------------------------------------------------------------------

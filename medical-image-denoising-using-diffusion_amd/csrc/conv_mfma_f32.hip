@@ -50,7 +50,7 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
 
     __shared__ f32x4 lds[2][NSLOT];
     __shared__ float fold_scratch[WM * WN * 2 * NT * 16];  // statistics: one row per wave
-    __shared__ stat_word stat_acc[(NTHREADS / 2 + 1) * STAT_WORDS];      // ... and the publish step's block accumulators
+    __shared__ stat_word stat_acc[(WN * NT * 16 + 2) * STAT_WORDS];      // ... and the publish step's block accumulators
     extern __shared__ float gnp[];                         // [2][Cin] GroupNorm scale, shift of this sample
 
     const int tid = threadIdx.x;
@@ -237,20 +237,16 @@ void conv_mfma_f32_kernel(const ConvArgs a) {
                 *reinterpret_cast<f32x4*>(wrow + wave * ROWF + NT * 16 + nt * 16 + kq * 4) = ssq[nt];
             }
         }
-        __syncthreads();
         constexpr int NCOL = WN * NT * 16;
-        float* const vals = reinterpret_cast<float*>(&lds[0][0]);            // [2][NCOL]; the staging buffers are idle now
-        for (int i = tid; i < 2 * NCOL; i += NTHREADS) {
+        auto fold = [&](int i) {             // fixed order over wm; stat_publish's first barrier publishes the rows
             const int which = i / NCOL, col = i - which * NCOL;
             const int wn_i = col / (NT * 16), c = col - wn_i * (NT * 16);
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < WM; ++m) t += wrow[(m * WN + wn_i) * ROWF + which * (NT * 16) + c];
-            vals[i] = t;
-        }
-        __syncthreads();
-        static_assert(sizeof(lds) >= 2 * NCOL * 4, "statistics scratch");
-        stat_publish_cols(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, trem % a.stat_rep, blockIdx.y * NCOL, NCOL, vals, stat_acc, tid, NTHREADS);
+            return t;
+        };
+        stat_publish(a.stat_tot, b, a.Cout, a.stat_bs, a.stat_rep, trem % a.stat_rep, blockIdx.y * NCOL, NCOL, fold, stat_acc, tid, NTHREADS);
     }
 }
 

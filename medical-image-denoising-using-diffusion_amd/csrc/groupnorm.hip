@@ -18,7 +18,7 @@ constexpr int GN_THREADS = 256;
 // are exact in fp64), rounds the block's sums to fp32 and adds them to the totals with exact integer atomics (stats_common.h).
 __global__ __launch_bounds__(GN_THREADS)
 void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int rep, int bs, int HW, int C, int rows) {
-    extern __shared__ double red[];               // [ppi][C][2] doubles, then [2][C] floats
+    extern __shared__ double red[];               // [ppi][C][2] doubles, then the block accumulators of stat_publish
     const int CQ = C >> 2;
     const int ppi = GN_THREADS / CQ;
     const int tid = threadIdx.x;
@@ -40,15 +40,14 @@ void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ to
             red[((size_t)pl * C + q * 4 + e) * 2 + 1] = ss[e];
         }
     }
-    __syncthreads();
-    float* const vals = reinterpret_cast<float*>(red + (size_t)ppi * C * 2);      // [2][C] behind the pixel-lane partials
-    for (int c = tid; c < C; c += GN_THREADS) {
-        double cs = 0, css = 0;
-        for (int l = 0; l < ppi; ++l) { cs += red[((size_t)l * C + c) * 2]; css += red[((size_t)l * C + c) * 2 + 1]; }
-        vals[c] = (float)cs; vals[C + c] = (float)css;
-    }
-    __syncthreads();
-    stat_publish_cols(tot, b, C, bs, rep, row % rep, 0, C, vals, reinterpret_cast<stat_word*>(red), tid, GN_THREADS);
+    // fixed-order fp64 sum over the pixel lanes, rounded once to fp32 (stat_publish's first barrier publishes `red`)
+    auto fold = [&](int i) {
+        const int which = i / C, c = i - which * C;
+        double t = 0;
+        for (int l = 0; l < ppi; ++l) t += red[((size_t)l * C + c) * 2 + which];
+        return (float)t;
+    };
+    stat_publish(tot, b, C, bs, rep, row % rep, 0, C, fold, reinterpret_cast<stat_word*>(red + (size_t)ppi * C * 2), tid, GN_THREADS);
 }
 
 int chan_partial_rows(int HW, int C) {
@@ -62,9 +61,7 @@ int chan_partial_rows(int HW, int C) {
 hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, hipStream_t s) {
     if (C % 4 || C / 4 > GN_THREADS) return hipErrorInvalidValue;
     const int ppi = GN_THREADS / (C / 4);
-    size_t lds = (size_t)ppi * C * 2 * sizeof(double);
-    if (lds < (size_t)(GN_THREADS / 2 + 1) * STAT_WORDS * sizeof(stat_word)) lds = (size_t)(GN_THREADS / 2 + 1) * STAT_WORDS * sizeof(stat_word);      // the publish step's block accumulators reuse it
-    lds += 2 * (size_t)C * sizeof(float);
+    const size_t lds = (size_t)ppi * C * 2 * sizeof(double) + (size_t)(C + 2) * STAT_WORDS * sizeof(stat_word);
     hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, tot, rep, bs, HW, C, rows);
     return hipGetLastError();
 }

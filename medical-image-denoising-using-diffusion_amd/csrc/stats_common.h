@@ -91,50 +91,69 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
     }
 }
 
-// Producer side, called by ALL threads of the workgroup (two barriers inside).  Thread i < 2 * ncol holds t = the
-// workgroup's partial sum (which = i / ncol: 0 sum, 1 sum of squares) of channel c0 + i % ncol of sample b.  The channels'
-// limbs are added per block of bs channels in LDS (ds_add_u64: exact), then one global atomic per non-zero block limb goes to
-// copy `replica` of tot [B][C/bs][rep][2][3].  lds_acc: >= (ncol + 1) * STAT_WORDS words of LDS nobody else is using.
-__device__ __forceinline__ void stat_publish(stat_word* __restrict__ tot, int b, int C, int bs, int rep, int replica,
-                                             int c0, int ncol, float t, stat_word* lds_acc, int tid, int nthreads) {
-    const int blk_first = c0 / bs, nblk = (c0 + ncol - 1) / bs - blk_first + 1;
-    for (int j = tid; j < nblk * STAT_WORDS; j += nthreads) lds_acc[j] = 0;
-    __syncthreads();
-    if (tid < 2 * ncol) {
-        const int which = tid / ncol, c = c0 + tid - which * ncol;
-        stat_word* slot = lds_acc + ((c / bs - blk_first) * 2 + which) * STAT_LIMBS;
-        const unsigned u = __float_as_uint(t);
-        const int ex = (int)((u >> 23) & 0xffu);
-        if (ex != 0) {                                              // zero (denormals are flushed: < 2^-126)
-            unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
-            int s = ex - 150 + 60;                                  // bit position of the mantissa's LSB in the fixed-point number
-            if (s < 0) { m = (s > -24) ? (m >> (-s)) : 0ull; s = 0; }
-            if (s > 95) s = 95;                                     // |t| >= 2^59 (never a finite activation statistic): pinned, no limb 3
-            const int k = s / 40, r = s - k * 40;
-            const unsigned long long x = m << r;                    // < 2^63
-            unsigned long long lo = x & ((1ull << 40) - 1ull), hi = x >> 40;
-            if (u >> 31) { lo = 0ull - lo; hi = 0ull - hi; }        // two's complement: limbs are signed accumulators
-            if (lo) atomicAdd(slot + k, lo);
-            if (hi) atomicAdd(slot + k + 1, hi);                    // k == 2 => r <= 15 => hi == 0
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < nblk * STAT_WORDS; j += nthreads) {
-        const stat_word v = lds_acc[j];
-        if (v) atomicAdd(tot + (((size_t)b * (C / bs) + blk_first + j / STAT_WORDS) * rep + replica) * STAT_WORDS + j % STAT_WORDS, v);
-    }
+// LDS stores / adds / barrier the compiler does not see as such.  While an LDS-DMA transfer is pending in hipcc's bookkeeping
+// (and an inline-asm s_waitcnt never clears it) every wait for a tracked vector load becomes vmcnt(0), a compiler-visible LDS
+// store may be preceded by one, and __syncthreads() carries a vmcnt(0) of its own -- and vmcnt counts stores too: at the end
+// of a convolution that is a wait for the tile's output stores to retire.  Only for LDS areas that are no DMA destination.
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void lds_store_raw(void* p, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(lds_offset(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_store_raw(void* p, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" ::"v"(lds_offset(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_store_raw(void* p, float __attribute__((ext_vector_type(4))) v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(lds_offset(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add_raw(unsigned long long* p, unsigned long long v) { asm volatile("ds_add_u64 %0, %1" ::"v"(lds_offset(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_barrier_raw() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
-// The same for a workgroup's whole slice: vals = LDS floats [2][ncol] (sums, then sums of squares, of channels c0 .. c0+ncol-1),
-// taken nthreads/2 columns at a time.  lds_acc must not overlap vals.
-__device__ __forceinline__ void stat_publish_cols(stat_word* __restrict__ tot, int b, int C, int bs, int rep, int replica,
-                                                  int c0, int ncol, const float* vals, stat_word* lds_acc, int tid, int nthreads) {
-    const int step = nthreads / 2;
-    for (int cb = 0; cb < ncol; cb += step) {
-        const int n = min(step, ncol - cb);
-        float t = 0.f;
-        if (tid < 2 * n) { const int which = tid / n; t = vals[which * ncol + cb + tid - which * n]; }
-        stat_publish(tot, b, C, bs, rep, replica, c0 + cb, n, t, lds_acc, tid, nthreads);
+// Exact conversion of an fp32 partial sum to the fixed-point limbs, added into LDS block accumulators: slot[0..2].
+__device__ __forceinline__ void stat_add_lds(stat_word* slot, float t) {
+    const unsigned u = __float_as_uint(t);
+    const int ex = (int)((u >> 23) & 0xffu);
+    if (ex == 0) return;                                        // zero (denormals are flushed: < 2^-126)
+    unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
+    int s = ex - 150 + 60;                                      // bit position of the mantissa's LSB in the fixed-point number
+    if (s < 0) { m = (s > -24) ? (m >> (-s)) : 0ull; s = 0; }
+    if (s > 95) s = 95;                                         // |t| >= 2^59 (never a finite activation statistic): pinned, no limb 3
+    const int k = s / 40, r = s - k * 40;
+    const unsigned long long x = m << r;                        // < 2^63
+    unsigned long long lo = x & ((1ull << 40) - 1ull), hi = x >> 40;
+    if (u >> 31) { lo = 0ull - lo; hi = 0ull - hi; }            // two's complement: limbs are signed accumulators
+    if (lo) lds_add_raw(slot + k, lo);
+    if (hi) lds_add_raw(slot + k + 1, hi);                      // k == 2 => r <= 15 => hi == 0
+}
+
+// Producer side, called by ALL threads of the workgroup; TWO barriers inside (the caller's LDS rows must have been written
+// with lds_store_raw or be otherwise complete: the barriers wait for lgkmcnt(0) only).  fold(i), i in [0, 2 * ncol), returns the
+// workgroup's partial sum (i / ncol: 0 sum, 1 sum of squares) of channel c0 + i % ncol of sample b -- typically a
+// fixed-order sum over the waves' rows in LDS, which the caller wrote BEFORE the call (the first barrier here publishes
+// them).  The channels' limbs are added per block of bs channels in LDS (ds_add_u64: exact), then one global atomic per
+// non-zero block limb goes to copy `replica` of tot [B][C/bs][rep][2][3].  lds_acc: >= (ncol / bs + 2) * STAT_WORDS words
+// of LDS nobody else is using (and not what fold() reads).
+template <class Fold>
+__device__ __forceinline__ void stat_publish(stat_word* __restrict__ tot, int b, int C, int bs, int rep, int replica,
+                                             int c0, int ncol, Fold fold, stat_word* lds_acc, int tid, int nthreads) {
+    const int blk_first = c0 / bs, nblk = (c0 + ncol - 1) / bs - blk_first + 1;
+    // raw LDS stores / barriers throughout: a compiler-visible LDS store or __syncthreads() after the kernel's LDS-DMA
+    // traffic would first wait for vmcnt(0) -- here that is the retirement of the tile's output stores (1-2 us per workgroup)
+    for (int j = tid; j < nblk * STAT_WORDS; j += nthreads) lds_store_raw(lds_acc + j, 0ull);
+    lds_barrier_raw();
+    for (int i = tid; i < 2 * ncol; i += nthreads) {
+        const int which = i / ncol, c = c0 + i - which * ncol;
+        stat_add_lds(lds_acc + ((c / bs - blk_first) * 2 + which) * STAT_LIMBS, fold(i));
+    }
+    lds_barrier_raw();
+    for (int j = tid; j < nblk * STAT_WORDS; j += nthreads) {
+        const stat_word v = lds_acc[j];
+#if defined(C16_ABL) && C16_ABL == 7      // ablation 7 (wrong results): plain stores instead of the global atomics
+        if (v) tot[(((size_t)b * (C / bs) + blk_first + j / STAT_WORDS) * rep + replica) * STAT_WORDS + j % STAT_WORDS] = v;
+#else
+        if (v) atomicAdd(tot + (((size_t)b * (C / bs) + blk_first + j / STAT_WORDS) * rep + replica) * STAT_WORDS + j % STAT_WORDS, v);
+#endif
     }
 }
 
