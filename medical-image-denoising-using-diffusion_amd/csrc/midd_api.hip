@@ -662,8 +662,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     };
 
     TensorRef h = bld.alloc(c.model_channels, H, W);
-    { Op o{}; o.kind = OP_IN_CONV; o.dst = h; g->ops.push_back(o); }
-    bld.ensure_stats(h);
+    { Op o{}; o.kind = OP_IN_CONV; bld.alloc_stats(h); o.dst = h; g->ops.push_back(o); }       // in_conv leaves its own totals
     g->outputs["in_conv"] = h;
     std::vector<TensorRef> skips;
     for (const Mod& m : p->downs) {
@@ -712,8 +711,8 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         }
         if (h.H != skip.H || h.W != skip.W) {                      // F.interpolate(..., bilinear) (DDIMModel.py:241-242)
             TensorRef o = bld.alloc(h.C, skip.H, skip.W);
+            bld.alloc_stats(o);                                    // the resize kernel leaves its own totals
             Op op{}; op.kind = OP_RESIZE; op.s0 = h; op.dst = o; g->ops.push_back(op);
-            bld.ensure_stats(o);
             h = o;
         }
         TensorRef o; if ((rc = run_rb(m, h, &skip, &o))) return rc;
@@ -857,8 +856,8 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
         }
         switch (o.kind) {
             case OP_IN_CONV:
-                e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), B, p->cfg.in_channels,
-                                   g->H, g->W, o.dst.C, s);
+                e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), T(o.dst.tot_off), g->stat_rep, o.dst.stat_bs,
+                                   B, p->cfg.in_channels, g->H, g->W, o.dst.C, s);
                 break;
             case OP_CHAN_TOT:
                 e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), g->stat_rep, o.s0.stat_bs, B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
@@ -890,7 +889,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                         : attention_launch(F(o.s0.off), F(o.dst.off), B, o.dst.H * o.dst.W, o.dst.C, 2, s);
                 break;
             case OP_RESIZE:
-                e = resize_bilinear_launch(F(o.s0.off), F(o.dst.off), B, o.s0.H, o.s0.W, o.s0.C, o.dst.H, o.dst.W, s);
+                e = resize_bilinear_launch(F(o.s0.off), F(o.dst.off), T(o.dst.tot_off), g->stat_rep, o.dst.stat_bs, B, o.s0.H, o.s0.W, o.s0.C, o.dst.H, o.dst.W, s);
                 break;
             case OP_CONVT:
                 e = conv_transpose_launch(F(o.s0.off), wd + o.w, wd + o.b, F(o.dst.off), B, o.s0.H, o.s0.W, o.s0.C, o.dst.C, s);

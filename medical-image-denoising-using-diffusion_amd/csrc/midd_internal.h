@@ -101,8 +101,9 @@ bool attention_supported(int head_dim);
 
 // ---------------------------------------------------------------- small direct kernels
 // in_conv: Conv3x3 on cat[x, cond] (NCHW [B,ic,H,W] each) -> NHWC [B][H][W][Cout]
+// tot != nullptr: also leaves the GroupNorm totals of the output [B][Cout/bs][rep][2][3] (stats_common.h)
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9][2ic][Cout]*/, const float* bias,
-                          float* out, int B, int ic, int H, int W, int Cout, hipStream_t s);
+                          float* out, stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, hipStream_t s);
 
 struct OutConvArgs {
     const float* src;       // NHWC [B][H][W][C]
@@ -120,7 +121,7 @@ struct OutConvArgs {
 hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s);
 
 // bilinear resize NHWC (align_corners=False), any size ratio
-hipError_t resize_bilinear_launch(const float* src, float* dst, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
+hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
 // ConvTranspose2d(C,C,4,stride=2,padding=1) direct (only used by topologies where it cannot be folded)
 hipError_t conv_transpose_launch(const float* src, const float* w /*[4][4][Cin][Cout]*/, const float* bias, float* dst,
                                  int B, int H, int W, int Cin, int Cout, hipStream_t s);

@@ -20,58 +20,106 @@ __device__ __forceinline__ float silu_pw(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
 }
 
+// ------------------------------------------------------------------------------ statistics of a pointwise producer
+// The two HBM-bound producers below also leave the GroupNorm totals of their output (stats_common.h) -- round 1/2 read the
+// tensor a second time for that (chan_total_kernel: 4 launches per forward).  A workgroup owns a pixel range of ONE sample;
+// thread = (pixel lane pl < ppi, channel group); each thread sums ITS NV channels over the pixels it walks (fp32, fixed
+// order), the lanes are folded per channel in fp64 in lane order, rounded once to fp32, and published with exact integer
+// atomics.  scratch: 2 * C * ppi floats of LDS; acc: (C + 2) * 6 words.
+template <int NV>
+__device__ __forceinline__ void pointwise_publish(const float (&sum)[NV], const float (&sq)[NV], bool active, int pl, int ppi, int cgrp,
+                                                  int C, float* scratch, stat_word* acc, stat_word* tot, int b, int bs, int rep,
+                                                  int replica, int tid) {
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            scratch[(size_t)(cgrp * NV + e) * ppi + pl] = sum[e];
+            scratch[(size_t)(C + cgrp * NV + e) * ppi + pl] = sq[e];
+        }
+    }
+    auto fold = [&](int i) {
+        double t = 0;
+        for (int l = 0; l < ppi; ++l) t += (double)scratch[(size_t)i * ppi + l];
+        return (float)t;
+    };
+    stat_publish(tot, b, C, bs, rep, replica, 0, C, fold, acc, tid, 256);
+}
+
+// pixels a workgroup of 256 threads walks: ~4 per pixel lane, at most 1024 workgroups per sample
+static int pointwise_rows(int HW, int ppi) {
+    int r = (HW + ppi * 4 - 1) / (ppi * 4);
+    return r < 1 ? 1 : (r > 1024 ? 1024 : r);
+}
+
 // ------------------------------------------------------------------------------ in_conv
-// thread = (pixel, 16 consecutive couts): the 18 input taps are loaded once per 16 outputs; weights
-// [9][2ic][Cout] and bias staged in LDS; a pixel's lanes write one contiguous 4*Cout-byte run.
+// thread = (pixel lane, 16 consecutive couts): the 18 input taps are loaded once per 16 outputs; weights
+// [9][2ic][Cout] and bias staged in LDS; a pixel's lanes write one contiguous 4*Cout-byte run.  grid (rows, B).
 __global__ __launch_bounds__(256)
 void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ w,
-                    const float* __restrict__ bias, float* __restrict__ out, int B, int ic, int H, int W, int Cout) {
-    extern __shared__ float wl[];                 // 9*2ic*Cout + Cout
+                    const float* __restrict__ bias, float* __restrict__ out, stat_word* __restrict__ tot, int rep, int bs,
+                    int ic, int H, int W, int Cout, int rows) {
+    extern __shared__ float wl[];                 // 9*2ic*Cout + Cout, then the statistics scratch
     const int nw = 9 * 2 * ic * Cout;
     for (int i = threadIdx.x; i < nw + Cout; i += 256) wl[i] = (i < nw) ? w[i] : bias[i - nw];
     __syncthreads();
     const int CG = Cout >> 4;                     // groups of 16 couts
-    const long total = (long)B * H * W * CG;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
-    const int cg = (int)(gid % CG);
-    const long pix = gid / CG;
-    const int ox = (int)(pix % W);
-    const int oy = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long)W * H));
-    f32x4 acc[4];
+    const int ppi = 256 / CG;
+    const int tid = threadIdx.x;
+    const int pl = tid / CG, cg = tid - pl * CG;
+    const bool active = pl < ppi;
+    const int b = blockIdx.y, row = blockIdx.x;
+    const int HW = H * W;
+    const int per = (HW + rows - 1) / rows;
+    const int p0 = row * per, p1 = min(HW, p0 + per);
+    float ssum[16], ssq[16];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = *reinterpret_cast<const f32x4*>(&wl[nw + cg * 16 + k * 4]);
-    for (int ci = 0; ci < 2 * ic; ++ci) {
-        const float* plane = (ci < ic) ? x + ((size_t)b * ic + ci) * H * W
-                                       : cond + ((size_t)b * ic + (ci - ic)) * H * W;
+    for (int k = 0; k < 16; ++k) { ssum[k] = 0.f; ssq[k] = 0.f; }
+    if (active) {
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            const int oy = p / W, ox = p - oy * W;
+            f32x4 acc[4];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int gy = oy + dy - 1;
-            if (gy < 0 || gy >= H) continue;
+            for (int k = 0; k < 4; ++k) acc[k] = *reinterpret_cast<const f32x4*>(&wl[nw + cg * 16 + k * 4]);
+            for (int ci = 0; ci < 2 * ic; ++ci) {
+                const float* plane = (ci < ic) ? x + ((size_t)b * ic + ci) * HW
+                                               : cond + ((size_t)b * ic + (ci - ic)) * HW;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int gx = ox + dx - 1;
-                if (gx < 0 || gx >= W) continue;
-                const float v = plane[(size_t)gy * W + gx];
-                const float* wr = &wl[((dy * 3 + dx) * 2 * ic + ci) * Cout + cg * 16];
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int gy = oy + dy - 1;
+                    if (gy < 0 || gy >= H) continue;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] += v * *reinterpret_cast<const f32x4*>(wr + k * 4);
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int gx = ox + dx - 1;
+                        if (gx < 0 || gx >= W) continue;
+                        const float v = plane[(size_t)gy * W + gx];
+                        const float* wr = &wl[((dy * 3 + dx) * 2 * ic + ci) * Cout + cg * 16];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] += v * *reinterpret_cast<const f32x4*>(wr + k * 4);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<f32x4*>(out + ((size_t)b * HW + p) * Cout + cg * 16 + k * 4) = acc[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ssum[k * 4 + e] += acc[k][e]; ssq[k * 4 + e] += acc[k][e] * acc[k][e]; }
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(out + (size_t)pix * Cout + cg * 16 + k * 4) = acc[k];
+    if (tot == nullptr) return;
+    float* const scratch = wl + nw + Cout;
+    stat_word* const acc_lds = reinterpret_cast<stat_word*>(scratch + 2 * (size_t)Cout * ppi + (((nw + Cout) & 1) ? 1 : 0));   // 8-byte aligned
+    pointwise_publish<16>(ssum, ssq, active, pl, ppi, cg, Cout, scratch, acc_lds, tot, b, bs, rep, row % rep, tid);
 }
 
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w, const float* bias, float* out,
-                          int B, int ic, int H, int W, int Cout, hipStream_t s) {
-    if (Cout % 16) return hipErrorInvalidValue;
-    const long total = (long)B * H * W * (Cout / 16);
-    const size_t lds = (size_t)(9 * 2 * ic * Cout + Cout) * sizeof(float);
+                          stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, hipStream_t s) {
+    if (Cout % 16 || Cout / 16 > 256) return hipErrorInvalidValue;
+    const int ppi = 256 / (Cout / 16);
+    const int rows = pointwise_rows(H * W, ppi);
+    const size_t lds = (size_t)(9 * 2 * ic * Cout + Cout + 2 * Cout * ppi + 2) * sizeof(float) + (size_t)(Cout + 2) * STAT_WORDS * sizeof(stat_word);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(in_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s,
-                       x, cond, w, bias, out, B, ic, H, W, Cout);
+    hipLaunchKernelGGL(in_conv_kernel, dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, ic, H, W, Cout, rows);
     return hipGetLastError();
 }
 
@@ -161,38 +209,54 @@ hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------ bilinear resize (NHWC)
 // Same index/weight arithmetic as ATen's upsample_bilinear2d with align_corners=False:
 //   src = max(0, scale*(dst+0.5)-0.5), scale = in/out;  i0 = floor(src), i1 = i0 + (i0 < in-1), l1 = src - i0.
+// grid (rows, B); also leaves the GroupNorm totals of its output (pointwise_publish)
 __global__ __launch_bounds__(256)
-void resize_bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                            int B, int H, int W, int C, int OH, int OW, float sy, float sx) {
+void resize_bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, stat_word* __restrict__ tot, int rep, int bs,
+                            int H, int W, int C, int OH, int OW, float sy, float sx, int rows) {
+    extern __shared__ float rs_lds[];             // statistics scratch
     const int CQ = C >> 2;
-    const long total = (long)B * OH * OW * CQ;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
-    const int cq = (int)(gid % CQ);
-    const long pix = gid / CQ;
-    const int ox = (int)(pix % OW);
-    const int oy = (int)((pix / OW) % OH);
-    const int b = (int)(pix / ((long)OW * OH));
-    float fy = sy * ((float)oy + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
-    float fx = sx * ((float)ox + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
-    const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-    const float* base = src + (size_t)b * H * W * C + cq * 4;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
-    const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-    *reinterpret_cast<f32x4*>(dst + (size_t)pix * C + cq * 4) = r;
+    const int ppi = 256 / CQ;
+    const int tid = threadIdx.x;
+    const int pl = tid / CQ, cq = tid - pl * CQ;
+    const bool active = pl < ppi;
+    const int b = blockIdx.y, row = blockIdx.x;
+    const int OHW = OH * OW;
+    const int per = (OHW + rows - 1) / rows;
+    const int p0 = row * per, p1 = min(OHW, p0 + per);
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const float* base = src + (size_t)b * H * W * C + cq * 4;
+        for (int p = p0 + pl; p < p1; p += ppi) {
+            const int oy = p / OW, ox = p - oy * OW;
+            float fy = sy * ((float)oy + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+            float fx = sx * ((float)ox + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+            const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
+            const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            *reinterpret_cast<f32x4*>(dst + ((size_t)b * OHW + p) * C + cq * 4) = r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ssum[e] += r[e]; ssq[e] += r[e] * r[e]; }
+        }
+    }
+    if (tot == nullptr) return;
+    stat_word* const acc_lds = reinterpret_cast<stat_word*>(rs_lds + 2 * (size_t)C * ppi);       // C % 4 == 0: 8-byte aligned
+    pointwise_publish<4>(ssum, ssq, active, pl, ppi, cq, C, rs_lds, acc_lds, tot, b, bs, rep, row % rep, tid);
 }
 
-hipError_t resize_bilinear_launch(const float* src, float* dst, int B, int H, int W, int C, int OH, int OW, hipStream_t s) {
-    if (C % 4) return hipErrorInvalidValue;
-    const long total = (long)B * OH * OW * (C / 4);
-    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       src, dst, B, H, W, C, OH, OW, (float)H / (float)OH, (float)W / (float)OW);
+hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, hipStream_t s) {
+    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
+    const int ppi = 256 / (C / 4);
+    const int rows = pointwise_rows(OH * OW, ppi);
+    const size_t lds = (size_t)2 * C * ppi * sizeof(float) + (size_t)(C + 2) * STAT_WORDS * sizeof(stat_word);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(rows, B), dim3(256), lds, s,
+                       src, dst, tot, rep, bs, H, W, C, OH, OW, (float)H / (float)OH, (float)W / (float)OW, rows);
     return hipGetLastError();
 }
 
