@@ -2,12 +2,11 @@
 Per queue: busy time and the gaps between consecutive kernels; over all queues: time with 0 / 1 / 2+ kernels resident."""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
+lo_f = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3   # kernels [lo_f, hi_f) of the trace by launch order: bench.py runs
+hi_f = float(sys.argv[3]) if len(sys.argv) > 3 else 0.7   # warm-up, the timed calls, then the per-launch-event leg
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), r["Kernel_Name"]) for r in rows if r["Kernel_Name"].startswith(("midd::", "void midd::", "_ZN4midd"))]
 ev.sort()
-t0, t1 = ev[0][0], max(e[1] for e in ev)
-lo = t0 + skip * (t1 - t0)                      # skip warm-up
-ev = [e for e in ev if e[0] >= lo]
+ev = ev[int(lo_f * len(ev)):int(hi_f * len(ev))]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 byq = collections.defaultdict(list)
 for e in ev: byq[e[2]].append(e)
