@@ -8,8 +8,6 @@ timeout -k 10 400 python3 bench.py > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 --latency-reps 0 > $OUT/kt.log 2>&1
 grep '^{"metric' $OUT/kt.log | tail -1 > $OUT/bench_under_rocprof.json
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-# (kernel tracing itself slows the two-stream run by ~20 %: occupancy under the tracer, not of the untraced bench)
-python3 tools/trace_gaps.py $(find $OUT/kt -name "*kernel_trace.csv" | head -1) > $OUT/stream_occupancy_under_tracer.txt 2>&1 || true
 CMD="python3 bench.py --steps 1 --warmup 0 --cpu-iters 0 --latency-reps 0 --inference-steps 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o pf --output-format csv -- $CMD > $OUT/pf.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o pw --output-format csv -- $CMD > $OUT/pw.log 2>&1
