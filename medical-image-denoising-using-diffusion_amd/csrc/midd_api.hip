@@ -260,7 +260,7 @@ extern "C" int mi_image_metrics(const void* target, const void* pred, int n, int
 
 // ------------------------------------------------------------------------------ C ABI: create / load
 extern "C" const char* mi_last_error(void) { return g_err; }
-extern "C" const char* mi_version(void) { return "midd 0.3 gfx950 (fp32 MFMA | split-fp16 x3 MFMA; device pre/post-processing)"; }
+extern "C" const char* mi_version(void) { return "midd 0.4 gfx950 (fp32 MFMA | split-fp16 x3 MFMA; GroupNorm statistics in the producers; device pre/post-processing)"; }
 
 extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
     if (!cfg || !out) return fail(MI_EINVAL, "null argument");

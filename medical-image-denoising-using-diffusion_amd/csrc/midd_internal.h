@@ -58,7 +58,7 @@ hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 
 // split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
 bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
-int conv16_wgs_per_img(int tiles, int B, int ny, int target = 0);   // target 0: MIDD_PERSIST_WGS or 768
+int conv16_wgs_per_img(int tiles, int B, int ny, int target = 0);   // target 0: 768
 bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t);   // ConvTile::tw == 0 marks it
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);      // persistent workgroups per sample (f16x3 kernels)
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
