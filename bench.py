@@ -126,6 +126,19 @@ def self_launch(args):
     raise SystemExit(0)
 
 
+def baseline_config_label(Bp, S, noise_steps, n_iters):
+    """Which BASELINE.json configuration a (per-GPU batch, size, schedule) corresponds to."""
+    if (Bp, S, noise_steps, n_iters) == (8, 256, 50, 50):
+        return "BASELINE.json configs[1]"
+    if (Bp, S, noise_steps, n_iters) == (32, 256, 100, 100):
+        return "BASELINE.json configs[2]"
+    if (Bp, S, noise_steps, n_iters) == (32, 256, 50, 50):
+        return "per-GPU shard of BASELINE.json configs[3]"
+    if (Bp, S, noise_steps, n_iters) == (8, 512, 50, 50):
+        return "per-GPU shard of BASELINE.json configs[4]"
+    return "not a BASELINE.json configuration"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,7 +215,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"batch={Bp}/GPU {S}x{S} grayscale, {n_iters}-iteration reverse loop "
                                f"(noise_steps={args.noise_steps}, inference_steps={args.inference_steps}), "
-                               "random-init 12.8M-param UNet (BASELINE.json configs[1])",
+                               f"random-init 12.8M-param UNet ({baseline_config_label(Bp, S, args.noise_steps, n_iters)})",
                    "batch_per_gpu": Bp, "global_batch": Bp * world, "image": [S, S], "iterations": n_iters,
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "collective": "one all_gather_into_tensor (RCCL) per step" if world > 1 else "none"},
