@@ -47,6 +47,11 @@ extern "C" {
 #define MI_COMPUTE_F32   0   /* fp32-input MFMA: bit-for-bit an fp32 fma chain */
 #define MI_COMPUTE_F16X3 1   /* fp32 operands split into two fp16 halves, three fp16 MFMAs, fp32 accumulate
                                 (~2^-21 relative per product; same parity gate) — about 5x the MFMA rate */
+/* OR into compute_mode: results of a sample do not depend on the batch it is computed in, bit for bit
+ * (denoise(x[:k]) == denoise(x)[:k]; SURVEY.md section 8e "sharded == single-GPU").  Tiles, persistent workgroups per
+ * sample and the attention key split are then chosen as for a batch of one -- the grouping of the fp32 partial sums
+ * behind the GroupNorm statistics no longer varies with the batch; costs throughput at large batches. */
+#define MI_COMPUTE_BATCH_INVARIANT 0x100
 
 /* sampler flags for mi_denoise */
 #define MI_CLAMP_EPS     1   /* clamp(eps,-5,5) before the update: DDIMModel.py:278 (absent in cddpm) */

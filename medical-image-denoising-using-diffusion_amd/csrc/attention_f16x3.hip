@@ -349,7 +349,7 @@ size_t attention16_scratch_bytes(int B, int N, int C) {
     return kv + part;
 }
 
-hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int N, int C, int heads, hipStream_t s) {
+hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int split_B, int N, int C, int heads, hipStream_t s) {
     const int D = C / heads;
     if (C % heads || !attention_supported(D) || D % 32 || heads != 2) return hipErrorInvalidValue;
     const float qscale = (float)((1.0 / sqrt((double)D)) * 1.4426950408889634);
@@ -367,7 +367,7 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
     const int qblocks = (N + A16_QB - 1) / A16_QB, tiles = (N + A16_KT - 1) / A16_KT;
     constexpr int want_wgs = 256;
     int ksplit = 1;
-    while ((long)qblocks * heads * B * ksplit < want_wgs && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
+    while ((long)qblocks * heads * split_B * ksplit < want_wgs && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
     const int tps = (tiles + ksplit - 1) / ksplit;
     if ((long)(ksplit - 1) * tps >= tiles) return hipErrorInvalidValue;        // every split owns at least one tile that starts below N
 #define MIDD_ATT(DD)                                                                                                        \

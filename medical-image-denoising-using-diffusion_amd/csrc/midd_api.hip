@@ -92,7 +92,8 @@ struct Program {
 };
 
 struct mi_plan {
-    mi_unet_cfg cfg{};
+    mi_unet_cfg cfg{};                                       // compute_mode holds the arithmetic only (flag bits stripped)
+    bool batch_invariant = false;                            // MI_COMPUTE_BATCH_INVARIANT: plan every launch as for a batch of one
     std::vector<Mod> downs, mid, ups;
     int final_c = 0, temb_cols = 0, levels = 0;
     std::vector<std::string> expected;                       // state-dict key order
@@ -271,7 +272,8 @@ extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
     if (cfg->num_res_blocks < 1) return fail(MI_EINVAL, "num_res_blocks must be >= 1");
     if (cfg->time_emb_dim < 1) return fail(MI_EINVAL, "time_emb_dim must be >= 1");
     if (cfg->variant != MI_VARIANT_DDIM && cfg->variant != MI_VARIANT_CDDPM) return fail(MI_EINVAL, "unknown variant %d", cfg->variant);
-    if (cfg->compute_mode != MI_COMPUTE_F32 && cfg->compute_mode != MI_COMPUTE_F16X3) return fail(MI_EINVAL, "unknown compute_mode %d", cfg->compute_mode);
+    const int arith = cfg->compute_mode & ~MI_COMPUTE_BATCH_INVARIANT;
+    if (arith != MI_COMPUTE_F32 && arith != MI_COMPUTE_F16X3) return fail(MI_EINVAL, "unknown compute_mode %d", cfg->compute_mode);
     for (int i = 0; i < cfg->num_levels; ++i)
         if (cfg->channel_mult[i] < 1) return fail(MI_EINVAL, "channel_mult[%d] must be >= 1", i);
     for (int i = 0; i < cfg->num_attention_levels; ++i) {
@@ -284,6 +286,8 @@ extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
     }
     std::unique_ptr<mi_plan> p(new mi_plan());
     p->cfg = *cfg;
+    p->cfg.compute_mode = arith;
+    p->batch_invariant = (cfg->compute_mode & MI_COMPUTE_BATCH_INVARIANT) != 0;
     int rc = build_topology(p.get());
     if (rc) return rc;
     *out = p.release();
@@ -599,9 +603,10 @@ struct Builder {
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col; o.gn = gn;
         if (gn.on) { if (int rcg = gn_consumer(s0, s1)) return rcg; }
         if (resid) { o.resid = *resid; o.has_resid = true; }
+        const int Bp = p->batch_invariant ? 1 : B;           // batch-invariant plans tile as for a batch of one
         const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
-                            ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, B, dst.H, dst.W, ks, stride, &o.tile)
-                            : conv_pick_tile(dst.C, B, dst.H, dst.W, ks, stride, &o.tile);
+                            ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile)
+                            : conv_pick_tile(dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
         if (want_stats) { alloc_stats(dst); o.want_stats = true; }
         o.dst = dst;
@@ -750,6 +755,9 @@ static int get_program(mi_plan* p, int B, int H, int W, Program** out, bool side
     if (it == p->programs.end()) {
         std::unique_ptr<Program> g(new Program());
         g->persist_wgs = side_by_side ? 640 : 0;
+        // batch-invariant: the persistent workgroups PER SAMPLE (and with them the grouping of the statistics' partial
+        // sums) must not depend on B: target / (B * ny) workgroups per sample with target = 768 B
+        if (p->batch_invariant) g->persist_wgs = 768 * B;
         int rc = build_program(p, B, H, W, g.get());
         if (rc) return rc;
         it = p->programs.emplace(key, std::move(g)).first;
@@ -885,7 +893,7 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
             }
             case OP_ATTN:
                 e = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
-                        ? attention16_launch(F(o.s0.off), F(o.dst.off), ws + o.partial_off, B, o.dst.H * o.dst.W, o.dst.C, 2, s)
+                        ? attention16_launch(F(o.s0.off), F(o.dst.off), ws + o.partial_off, B, p->batch_invariant ? 1 : B, o.dst.H * o.dst.W, o.dst.C, 2, s)
                         : attention_launch(F(o.s0.off), F(o.dst.off), B, o.dst.H * o.dst.W, o.dst.C, 2, s);
                 break;
             case OP_RESIZE:

@@ -95,7 +95,8 @@ hipError_t metrics_launch(const float* target, const float* pred, int n, int h, 
 // qkv: NHWC [B][N][3C], channel = s*C + head*D + d (s in q,k,v);  out: [B][N][C]
 hipError_t attention_launch(const float* qkv, float* out, int B, int N, int C, int heads, hipStream_t s);
 // split-fp16 variant; `scratch` (attention16_scratch_bytes) holds the pre-split K and V^T images
-hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int N, int C, int heads, hipStream_t s);
+// split_B: the batch the key split is chosen for (B, or 1 for batch-invariant plans)
+hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int split_B, int N, int C, int heads, hipStream_t s);
 size_t attention16_scratch_bytes(int B, int N, int C);
 bool attention_supported(int head_dim);
 

@@ -57,8 +57,13 @@ def _default_init(name: str, shape: Tuple[int, ...], all_shapes: Dict[str, Tuple
 
 class UNetDiffusion(nn.Module):
     def __init__(self, in_channels=1, model_channels=48, channel_mult=(1, 2, 3, 4), num_res_blocks=2,
-                 attention_resolutions=(3,), dropout=0.0, time_emb_dim=192, variant="ddim", compute=None):
+                 attention_resolutions=(3,), dropout=0.0, time_emb_dim=192, variant="ddim", compute=None,
+                 batch_invariant=None):
         super().__init__()
+        # batch_invariant (not a reference argument; env MIDD_BATCH_INVARIANT=1): a sample's result does not depend on the
+        # batch it is computed in, bit for bit (denoise(x[:k]) == denoise(x)[:k]) -- every launch is planned as for a batch of
+        # one, which costs throughput at large batches.  Default off: results are then reproducible per (batch size, image size).
+        self.batch_invariant = bool(int(os.environ.get("MIDD_BATCH_INVARIANT", "0"))) if batch_invariant is None else bool(batch_invariant)
         # arithmetic of the MFMA contractions: "f16x3" (split-fp16, default) or "f32" (fp32-input MFMA)
         self.compute = compute or os.environ.get("MIDD_COMPUTE", "f16x3")
         if self.compute not in native.MI_COMPUTE:
@@ -113,7 +118,7 @@ class UNetDiffusion(nn.Module):
             for i, a in enumerate(c.attention_resolutions):
                 cfg.attention_levels[i] = a
             cfg.time_emb_dim, cfg.variant = c.time_emb_dim, native.MI_VARIANT[c.variant]
-            cfg.compute_mode = native.MI_COMPUTE[self.compute]
+            cfg.compute_mode = native.MI_COMPUTE[self.compute] | (native.MI_COMPUTE_BATCH_INVARIANT if self.batch_invariant else 0)
             handle = C.c_void_p()
             native.check(lib.mi_unet_plan_create(C.byref(cfg), C.byref(handle)))
             self._plan = handle.value

@@ -17,6 +17,7 @@ MI_MAX_LEVELS = 8
 MI_VARIANT = {"ddim": 0, "cddpm": 1}
 MI_CLAMP_EPS = 1
 MI_COMPUTE = {"f32": 0, "f16x3": 1}
+MI_COMPUTE_BATCH_INVARIANT = 0x100          # include/midd.h: OR into compute_mode
 
 
 class NativeLibraryError(RuntimeError):
