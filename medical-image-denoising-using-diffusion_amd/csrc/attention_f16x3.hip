@@ -40,6 +40,7 @@ constexpr int A16_QB = 4 * A16_QW;         // queries per workgroup
 constexpr int A16_MAX_SPLIT = 8;
 constexpr float A16_QKV_SCALE = 16.0f;     // 2^4
 constexpr float A16_P_SCALE = 1024.0f;     // 2^10
+constexpr float A16_P_SHIFT = 10.0f;       // log2 of it: folded into the softmax exponent
 
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -129,8 +130,21 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kq = lane >> 4;
-    const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
-    const int qb = blockIdx.x / ksplit, ks = blockIdx.x - qb * ksplit;
+    // XCD-aware mapping.  Workgroups are dealt round-robin to the 8 XCDs in linear order (x fastest), each XCD has its own
+    // 4 MB L2, and every workgroup of a (sample, head) pair streams that pair's whole K / V image (3.1 MB at N = 4096):
+    // in launch order a pair's workgroups land on all XCDs and every L2 sees every pair (25 MB at B = 4) -- the K / V tiles
+    // come from the fabric each time (786 MB per launch at N = 4096).  Remapped, a pair's workgroups share ONE XCD (8 or
+    // more pairs) or an equal share of them (1, 2, 4 pairs), and its image stays in that L2.
+    const int heads = gridDim.y;
+    int bx = blockIdx.x, pair = blockIdx.y + gridDim.y * blockIdx.z;
+    {
+        const int X = gridDim.x, P = gridDim.y * gridDim.z;
+        const int L = blockIdx.x + X * pair, xcd = L & 7, k = L >> 3;
+        if (P % 8 == 0) { pair = xcd + 8 * (k / X); bx = k % X; }
+        else if (8 % P == 0 && X % (8 / P) == 0) { const int r = 8 / P; pair = xcd / r; bx = k * r + xcd % r; }
+    }
+    const int head = pair % heads, b = pair / heads;
+    const int qb = bx / ksplit, ks = bx - qb * ksplit;
     const int q0 = qb * A16_QB + wave * A16_QW;
     const int C3 = 3 * C;
     const float* base = qkv + (size_t)b * N * C3;
@@ -234,7 +248,11 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
             }
         }
 
-        // online softmax (base-2 domain); lane: query l16 of tile qm, keys kt0 + 16kb + 4kq + r
+        // online softmax (base-2 domain); lane: query l16 of tile qm, keys kt0 + 16kb + 4kq + r.  The kernel is bound by the
+        // vector ALU, not by the MFMAs (round 2: ~300 vector instructions per 72 MFMAs), so: the key-bound mask only in
+        // the tile that crosses N, the 2^10 operand prescale of P folded into the exponent, and O rescaled only when some
+        // lane's running maximum moved (after the first tiles it rarely does).
+        const bool tail = kt0 + A16_KT > N;                   // uniform
         half8 ph[QM], pl[QM];
 #pragma unroll
         for (int qm = 0; qm < QM; ++qm) {
@@ -242,33 +260,38 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb) {
                 st[qm][kb] = st[qm][kb] * (1.0f / (A16_QKV_SCALE * A16_QKV_SCALE));
+                if (tail) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (kt0 + kb * 16 + kq * 4 + r >= N) st[qm][kb][r] = -INFINITY;
-                    tmax = fmaxf(tmax, st[qm][kb][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (kt0 + kb * 16 + kq * 4 + r >= N) st[qm][kb][r] = -INFINITY;
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[qm][kb][r]);
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
             const float m_new = fmaxf(m[qm], tmax);           // finite: the first key of every tile is < N
             const float alpha = __builtin_amdgcn_exp2f(m[qm] - m_new);
+            const float mshift = m_new - A16_P_SHIFT;         // exp2(s - mshift) = 2^10 exp2(s - m_new): P arrives prescaled
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(st[qm][kb][r] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(st[qm][kb][r] - mshift);
                     psum += p;
                     _Float16 h_, l_;
-                    split1(p * A16_P_SCALE, h_, l_);
+                    split1(p, h_, l_);
                     ph[qm][kb * 4 + r] = h_; pl[qm][kb * 4 + r] = l_;
                 }
             psum += __shfl_xor(psum, 16);
             psum += __shfl_xor(psum, 32);
-            l[qm] = l[qm] * alpha + psum;
+            l[qm] = l[qm] * alpha + psum;                     // in units of 2^-10 (undone once, after the loop)
             m[qm] = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
 #pragma unroll
-            for (int tt = 0; tt < DT; ++tt) o[qm][tt] *= alpha;
+                for (int tt = 0; tt < DT; ++tt) o[qm][tt] *= alpha;
+            }
         }
 
         // O^T += V^T . P^T over the tile's 32 keys
@@ -292,6 +315,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     // O^T accumulator: col = query l16, row = d = 16t + 4kq + r
 #pragma unroll
     for (int qm = 0; qm < QM; ++qm) {
+        l[qm] *= (1.0f / A16_P_SCALE);                        // exact: back to the unscaled row sum
         const int qi = q0 + qm * 16 + l16;
         if (qi >= N) continue;
         if (ksplit == 1) {
@@ -363,11 +387,13 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
     hipLaunchKernelGGL(attention_prep_kernel, dim3(Npad / 32, heads, B), dim3(256), 0, s, qkv, Kp, Vp, N, Npad, C, D, heads);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // split the keys until 256 workgroups exist (one per CU; a 512 target measured slower), keeping at least two 32-key tiles per split
+    // Split the keys (flash-decoding) for occupancy: up to two workgroups per CU (what the LDS allows) while a split keeps
+    // >= 16 tiles of 32 keys (N = 4096: 375 -> 326 us per attention block), then up to one per CU down to two tiles per
+    // split (a 512 target with short splits measured slower at N = 1024).
     const int qblocks = (N + A16_QB - 1) / A16_QB, tiles = (N + A16_KT - 1) / A16_KT;
-    constexpr int want_wgs = 256;
     int ksplit = 1;
-    while ((long)qblocks * heads * split_B * ksplit < want_wgs && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
+    while ((long)qblocks * heads * split_B * ksplit < 512 && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 16) ksplit *= 2;
+    while ((long)qblocks * heads * split_B * ksplit < 256 && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
     const int tps = (tiles + ksplit - 1) / ksplit;
     if ((long)(ksplit - 1) * tps >= tiles) return hipErrorInvalidValue;        // every split owns at least one tile that starts below N
 #define MIDD_ATT(DD)                                                                                                        \
