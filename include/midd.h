@@ -37,6 +37,11 @@ extern "C" {
 #define MI_ESTATE       -2   /* call order (e.g. forward before finalize, missing weight) */
 #define MI_EHIP         -3   /* a HIP runtime call or kernel launch failed */
 #define MI_ENOMEM       -4   /* workspace too small */
+#define MI_ERANGE       -5   /* mi_status: the last call met values outside what its arithmetic represents */
+
+/* bits of the status word (mi_status) */
+#define MI_STATUS_NONFINITE   1   /* NaN / Inf activations reached a GroupNorm statistic or a raw conv operand */
+#define MI_STATUS_FP16_RANGE  2   /* split-fp16 mode: an attention operand (q, k, v) beyond +-4094 */
 
 #define MI_MAX_LEVELS    8
 
@@ -121,11 +126,27 @@ int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, in
                const float* step_noise, int flags,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Status of the last mi_unet_forward / mi_denoise call that used `workspace` (its first word; the calls clear it when they
+ * start).  SYNCHRONISES `stream` (one 4-byte device-to-host copy).  Returns MI_OK with *flags == 0, or MI_ERANGE with the
+ * MI_STATUS_* bits in *flags: the kernels never turn a NaN / Inf activation or an operand beyond the split-fp16 range into
+ * finite garbage silently -- the output is NaN where the reference's is, and this call says why.  (The reference itself
+ * reports nothing: torch propagates NaN, DDIMModel.py:219-289.) */
+int mi_status(const void* workspace, void* stream, int* flags);
+
 /* Debug/test hook: after a forward call, copies the output of the named top-level module
  * (e.g. "downs.3", "mid_attn", "ups.6") from the workspace to `dst` (device fp32, NCHW
  * [B,C,h,w]); returns its C,h,w.  `dst` may be NULL to query the shape only. */
 int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int H, int W,
                    const void* workspace, float* dst, int* C, int* h, int* w, void* stream);
+
+/* Debug/test hook, host only (no GPU call): the key split the split-fp16 attention kernel uses for N keys (pixels of
+ * the attention level) when the execution program holds B samples: number of splits and 32-key tiles per split.
+ * Every split owns at least one tile for every N >= 1 (tests sweep it). */
+int mi_debug_attention_split(int N, int B, int* ksplit, int* tiles_per_split);
+
+/* First 16 hex digits of the sha256 over the kernel sources (csrc/ *.h, *.hip) this library was BUILT from, embedded at
+ * build time: what bench.py / tools/pmc_traffic.py compare profiles against (not the working tree). */
+const char* mi_source_hash(void);
 
 /* Per-kernel timing with HIP events on the caller's stream (bench.py's roofline leg; the
  * reference's only timer for this path is time.time() around denoise(), DDIMModel.py:495-498).

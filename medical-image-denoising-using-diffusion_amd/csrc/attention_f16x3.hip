@@ -1,6 +1,5 @@
 // Fused self-attention on split-fp16 MFMAs (three v_mfma_f32_16x16x32_f16 per product, fp32
-// accumulate) — the f16x3 counterpart of attention_f32.hip, same interface and the same
-// transposed-score trick.
+// accumulate) — the f16x3 counterpart of attention_f32.hip, same transposed-score trick.
 //
 // Replaces AttentionBlock.forward's matmul / softmax / matmul
 // (/root/reference/Backend/DDIM/DDIMModel.py:149-162; heads = 2, head_dim = C/2, q scaled by
@@ -9,22 +8,26 @@
 //
 //   S^T[key][q] = K . Q^T   A = K rows (16 B = 8 consecutive d per lane), B = Q^T from registers
 //   P           = exp2(S^T - m)  online softmax; the lane that owns a query column owns its m, l
-//   O^T[d][q]  += V^T . P^T  A = V^T (pre-transposed image), B = P^T straight from the score accumulators:
+//   O^T[d][q]  += V^T . P^T  A = V^T, B = P^T straight from the score accumulators:
 //                            the 32-wide k index of this MFMA is permuted so that element j of lane group kq
 //                            is key 16*(j>>2)+4*kq+(j&3) of the key pair-block — the keys the lane already holds.
 // Every fp32 operand x is used as x*2^s = hi + lo (fp16 each, exact power-of-two prescale):
 // q,k,v: s = 4; p in [0,1]: s = 10; hi.hi + hi.lo + lo.hi reproduces the fp32 product to ~2^-21.
 //
-// Structure (round 2; the round-1 kernel ran 128 workgroups of 4 x 16 queries on 256 CUs and every one of them
-// re-read the whole K / V image through register-staged copies with two barriers per tile):
-//   * workgroup = 4 waves x 32 queries (two 16-query MFMA column tiles per wave): every K / V^T fragment read
-//     from LDS feeds six MFMAs instead of three;
-//   * the keys are split `ksplit` ways over workgroups (flash-decoding style) so that ~512 workgroups exist at any
-//     batch size; each split leaves (m, l, unnormalised O^T) and attention_combine_kernel merges them in split
-//     order (deterministic);
-//   * K / V^T tiles of 32 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+// Structure:
+//   * workgroup = 4 waves x 32 queries (two 16-query MFMA column tiles per wave): every K / V fragment read
+//     from LDS feeds six MFMAs;
+//   * the keys are split `ksplit` ways over workgroups (flash-decoding style) so that ~256-512 workgroups exist at any
+//     batch size; each split leaves (m, l, unnormalised O^T);
+//   * K / V tiles of 32 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
 //     instruction, per-lane source addresses so the padded, conflict-free LDS rows need no padded global
 //     image) into a two-stage ring: one barrier per tile, the next tile in flight under the MFMAs.
+// Round 3: the attention block is THREE launches (it was five).  The qkv projection's epilogue writes q (fp32 [B][N][C]) and
+// the split-fp16 K and V images this kernel stages (conv1x1_f16x3.hip, ATT_QKV_OUT) -- attention_prep_kernel is gone, and
+// so is the transposed V image: V is staged [key][d] like K and its MFMA A fragments (V^T) come from ds_read_b64_tr_b16,
+// the transposing LDS read (each 16-lane group reads a 4-key x 16-d block and receives it d-major).  The partials are
+// ALWAYS written (also for one split) and combined by the output projection while it loads its operand
+// (conv1x1_f16x3.hip, ATT_PART_IN) -- attention_combine_kernel and the normalised [B][N][C] tensor are gone.
 #include "midd_internal.h"
 #include <cstdlib>
 
@@ -47,77 +50,37 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+// hi = fp16(x) pairs by v_cvt_pk_f16_f32, lo = fp16(x - hi) by v_fma_mix{lo,hi}_f16 (f16x3_common.h: split_pair)
+__device__ __forceinline__ void att_split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 h;
+    h[0] = (_Float16)x0; h[1] = (_Float16)x1;
+    hi = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
+}
+
 __device__ __forceinline__ void att_dma16(const void* gsrc, char* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)gsrc,
                                      (void __attribute__((address_space(3)))*)lds_dst_wave_base, 16, 0, 0);
 }
 
-// Pre-split pass: K and V of every (sample, head) are converted ONCE to the fp16 hi/lo images the
-// attention kernel stages (instead of once per query block):
-//   Kp [B][heads][2 (hi,lo)][Npad][D]   Vp [B][heads][2][D][Npad]   (V transposed; Npad = N rounded up to 64; keys >= N are zeros)
-__global__ __launch_bounds__(256)
-void attention_prep_kernel(const float* __restrict__ qkv, _Float16* __restrict__ Kp, _Float16* __restrict__ Vp,
-                           int N, int Npad, int C, int D, int heads) {
-    const int b = blockIdx.z, head = blockIdx.y;
-    const int C3 = 3 * C;
-    const float* base = qkv + (size_t)b * N * C3;
-    const int kcol = C + head * D, vcol = 2 * C + head * D;
-    _Float16* kh = Kp + ((size_t)(b * heads + head) * 2) * Npad * D;
-    _Float16* kl = kh + (size_t)Npad * D;
-    _Float16* vh = Vp + ((size_t)(b * heads + head) * 2) * D * Npad;
-    _Float16* vl = vh + (size_t)D * Npad;
-    const int key0 = blockIdx.x * 32;
-    __shared__ float vt[32][128 + 1];
-    // K: float4 along d; V: staged for the transpose in the same pass
-    for (int idx = threadIdx.x; idx < 32 * (D / 4); idx += 256) {
-        const int kk = idx / (D / 4), dq = idx % (D / 4);
-        const int key = key0 + kk;
-        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-        if (key < N) {
-            kv = *reinterpret_cast<const f32x4*>(base + (size_t)key * C3 + kcol + dq * 4);
-            v = *reinterpret_cast<const f32x4*>(base + (size_t)key * C3 + vcol + dq * 4);
-        }
-        half4 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { _Float16 h_, l_; split1(kv[e] * A16_QKV_SCALE, h_, l_); hi[e] = h_; lo[e] = l_; }
-        *reinterpret_cast<half4*>(kh + (size_t)key * D + dq * 4) = hi;
-        *reinterpret_cast<half4*>(kl + (size_t)key * D + dq * 4) = lo;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vt[kk][dq * 4 + e] = v[e] * A16_QKV_SCALE;
-    }
-    __syncthreads();
-    // V^T: each thread writes 8 consecutive keys (16 bytes) of one d-row per plane
-    for (int idx = threadIdx.x; idx < D * 4; idx += 256) {
-        const int d = idx >> 2, k8 = idx & 3;
-        half8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { _Float16 h_, l_; split1(vt[k8 * 8 + j][d], h_, l_); hi[j] = h_; lo[j] = l_; }
-        *reinterpret_cast<half8*>(vh + (size_t)d * Npad + key0 + k8 * 8) = hi;
-        *reinterpret_cast<half8*>(vl + (size_t)d * Npad + key0 + k8 * 8) = lo;
-    }
-}
-
 template <int D>
 struct Att16Geom {
-    static constexpr int KCH = D / 8 + 2;                  // 16-byte chunks per K row in LDS: D halfs + 16 pad (224-B rows at D = 96: conflict-free b128 reads)
-    static constexpr int KROW = KCH * 16;                  // bytes
-    static constexpr int VCH = A16_KT / 8 + 1;             // chunks per V^T row: 32 keys + 8 pad (80-B rows: conflict-free b64 reads)
-    static constexpr int VROW = VCH * 16;
-    static constexpr int KCHUNKS = 2 * A16_KT * KCH;       // both planes
-    static constexpr int VCHUNKS = 2 * D * VCH;
-    static constexpr int KPLANE = A16_KT * KROW;           // bytes of one K plane
-    static constexpr int VPLANE = D * VROW;
-    static constexpr int KBYTES = 2 * KPLANE, VBYTES = 2 * VPLANE;
-    static constexpr int PIECES = (KCHUNKS + VCHUNKS) / 64;
+    static constexpr int KCH = D / 8 + 2;                  // 16-byte chunks per K / V row in LDS: D halfs + 16 pad (224-B rows at D = 96:
+    static constexpr int KROW = KCH * 16;                  //   conflict-free ds_read_b128 row reads AND ds_read_b64_tr_b16 block reads)
+    static constexpr int KPLANE = A16_KT * KROW;           // bytes of one plane (hi or lo) of a 32-key tile
+    static constexpr int STAGE = 4 * KPLANE;               // K hi | K lo | V hi | V lo
+    static constexpr int CHUNKS = 4 * A16_KT * KCH;
+    static constexpr int PIECES = CHUNKS / 64;             // 1 KiB DMA pieces per stage (= 2 KCH)
     static constexpr int PPW = (PIECES + 3) / 4;           // per wave
-    static constexpr int STAGE = KBYTES + VBYTES;
-    static_assert(KCHUNKS % 64 == 0 && VCHUNKS % 64 == 0, "a DMA piece must not straddle the K / V images");
+    static_assert(CHUNKS % 64 == 0, "whole DMA pieces");
 };
 
 template <int D>
 __global__ __launch_bounds__(256, 2)
-void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vp,
-                            float* __restrict__ out, float* __restrict__ part_o, float* __restrict__ part_ml,
+void attention_f16x3_kernel(const float* __restrict__ q, const _Float16* __restrict__ Kp, const _Float16* __restrict__ Vp,
+                            float* __restrict__ part_o, float* __restrict__ part_ml,
                             int N, int Npad, int C, float qscale, int ksplit, int tiles_per_split) {
     using G = Att16Geom<D>;
     constexpr int DC = D / 32;                 // 32-wide k chunks of the head dimension (QK^T)
@@ -125,7 +88,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     constexpr int QM = A16_QW / 16;            // 16-query column tiles per wave
     constexpr int KB = A16_KT / 16;            // 16-key blocks per tile
     static_assert(D % 32 == 0 && KB == 2, "head_dim must be a multiple of 32; one 32-key pair-block per tile");
-    extern __shared__ __attribute__((aligned(16))) char lds[];            // two stages of [K hi | K lo | V^T hi | V^T lo]
+    extern __shared__ __attribute__((aligned(16))) char lds[];            // two stages of [K hi | K lo | V hi | V lo], rows = keys
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,15 +109,15 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     const int head = pair % heads, b = pair / heads;
     const int qb = bx / ksplit, ks = bx - qb * ksplit;
     const int q0 = qb * A16_QB + wave * A16_QW;
-    const int C3 = 3 * C;
-    const float* base = qkv + (size_t)b * N * C3;
+    const float* base = q + (size_t)b * N * C;                       // q: fp32 [B][N][C] (the qkv projection's epilogue)
     const int qcol = head * D;
-    const char* gk = reinterpret_cast<const char*>(Kp + ((size_t)(b * heads + head) * 2) * Npad * D);
-    const char* gv = reinterpret_cast<const char*>(Vp + ((size_t)(b * heads + head) * 2) * D * Npad);
+    const char* gk = reinterpret_cast<const char*>(Kp + ((size_t)(b * heads + head) * 2) * Npad * D);     // [hi|lo][Npad][D]
+    const char* gv = reinterpret_cast<const char*>(Vp + ((size_t)(b * heads + head) * 2) * Npad * D);
     const int ntiles = (N + A16_KT - 1) / A16_KT;
     const int t_begin = ks * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
 
     // ---- DMA plan: piece p (1 KiB of the stage image) = chunks 64p .. 64p+63; this lane's chunk -> global source ----
+    // chunk c = ((plane4 * 32 + key) * KCH + ch): plane4 = K hi, K lo, V hi, V lo; ch >= D/8 is row padding (dummy source)
     const char* src[G::PPW];
     int adv[G::PPW];                           // bytes the source moves per tile
 #pragma unroll
@@ -162,15 +125,13 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
         const int piece = wave + 4 * i;
         const int c = piece * 64 + lane;
         const char* s = gk; int a = 0;
-        if (c < G::KCHUNKS) {
-            const int plane = c / (A16_KT * G::KCH), rem = c - plane * (A16_KT * G::KCH);
+        if (c < G::CHUNKS) {
+            const int plane4 = c / (A16_KT * G::KCH), rem = c - plane4 * (A16_KT * G::KCH);
             const int key = rem / G::KCH, ch = rem - key * G::KCH;
-            if (ch < D / 8) { s = gk + ((size_t)plane * Npad + key) * (D * 2) + ch * 16; a = A16_KT * D * 2; }
-        } else if (c < G::KCHUNKS + G::VCHUNKS) {
-            const int cv = c - G::KCHUNKS;
-            const int plane = cv / (D * G::VCH), rem = cv - plane * (D * G::VCH);
-            const int d = rem / G::VCH, ch = rem - d * G::VCH;
-            if (ch < A16_KT / 8) { s = gv + ((size_t)plane * D + d) * ((size_t)Npad * 2) + ch * 16; a = A16_KT * 2; }
+            if (ch < D / 8) {
+                s = (plane4 < 2 ? gk : gv) + ((size_t)(plane4 & 1) * Npad + key) * (D * 2) + ch * 16;
+                a = A16_KT * D * 2;
+            }
         }
         src[i] = s + (size_t)t_begin * a; adv[i] = a;                     // pad chunks: a valid dummy source, never read back
     }
@@ -195,7 +156,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (qi < N) v = *reinterpret_cast<const f32x4*>(base + (size_t)qi * C3 + qcol + c * 32 + kq * 8 + h * 4);
+                if (qi < N) v = *reinterpret_cast<const f32x4*>(base + (size_t)qi * C + qcol + c * 32 + kq * 8 + h * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     _Float16 hi, lo;
@@ -216,7 +177,14 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
     for (int qm = 0; qm < QM; ++qm) { m[qm] = -INFINITY; l[qm] = 0.f; }
 
     const int koff = l16 * G::KROW + kq * 16;                 // K fragment: row = key l16 of the block, 8 halfs at d = 32c + 8kq
-    const int voff = l16 * G::VROW + kq * 8;                  // V^T fragment: row = d l16 of the tile, keys 4kq.. and 16+4kq..
+    // V^T fragment by the transposing read: the 16 lanes of group kq read the block keys 4kq .. 4kq+3 (+16: second half)
+    // x d 16t .. 16t+15; lane 4r+p supplies the address of row (key) r, columns 4p .. 4p+3, and lane l16 receives column
+    // d = 16t + l16 of the four keys -- the A operand V^T[d][keys 4kq.., 16+4kq..] of the permuted-k PV product
+    const int voff = (kq * 4 + (l16 >> 2)) * G::KROW + (l16 & 3) * 8;
+    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    auto tr_read = [&](const char* p) {
+        return __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p)));
+    };
 
     for (int t = t_begin; t < t_end; ++t) {
         const int stage = (t - t_begin) & 1;
@@ -225,7 +193,7 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
         asm volatile("" ::: "memory");
         if (t + 1 < t_end) issue(stage ^ 1);
         const char* Kh = lds + stage * G::STAGE;
-        const char* Vh = Kh + G::KBYTES;
+        const char* Vh = Kh + 2 * G::KPLANE;
         const int kt0 = t * A16_KT;
 
         // S^T = K . Q^T (x 2^8): rows = keys, cols = queries
@@ -274,16 +242,18 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
             const float alpha = __builtin_amdgcn_exp2f(m[qm] - m_new);
             const float mshift = m_new - A16_P_SHIFT;         // exp2(s - mshift) = 2^10 exp2(s - m_new): P arrives prescaled
             float psum = 0.f;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 phw, plw;
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
+            for (int kb = 0; kb < KB; ++kb) {
+                float pv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(st[qm][kb][r] - mshift);
-                    psum += p;
-                    _Float16 h_, l_;
-                    split1(p, h_, l_);
-                    ph[qm][kb * 4 + r] = h_; pl[qm][kb * 4 + r] = l_;
-                }
+                for (int r = 0; r < 4; ++r) { pv[r] = __builtin_amdgcn_exp2f(st[qm][kb][r] - mshift); psum += pv[r]; }
+                unsigned hh, ll;
+                att_split_pair(pv[0], pv[1], hh, ll); phw[kb * 2] = hh; plw[kb * 2] = ll;
+                att_split_pair(pv[2], pv[3], hh, ll); phw[kb * 2 + 1] = hh; plw[kb * 2 + 1] = ll;
+            }
+            ph[qm] = __builtin_bit_cast(half8, phw); pl[qm] = __builtin_bit_cast(half8, plw);
             psum += __shfl_xor(psum, 16);
             psum += __shfl_xor(psum, 32);
             l[qm] = l[qm] * alpha + psum;                     // in units of 2^-10 (undone once, after the loop)
@@ -297,10 +267,10 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
         // O^T += V^T . P^T over the tile's 32 keys
 #pragma unroll
         for (int tt = 0; tt < DT; ++tt) {
-            const int off = tt * 16 * G::VROW + voff;
+            const char* vp = Vh + voff + tt * 32;
+            const half4 vh0 = tr_read(vp), vh1 = tr_read(vp + 16 * G::KROW);
+            const half4 vl0 = tr_read(vp + G::KPLANE), vl1 = tr_read(vp + G::KPLANE + 16 * G::KROW);
             half8 vh, vl;
-            const half4 vh0 = *reinterpret_cast<const half4*>(Vh + off), vh1 = *reinterpret_cast<const half4*>(Vh + off + 32);
-            const half4 vl0 = *reinterpret_cast<const half4*>(Vh + G::VPLANE + off), vl1 = *reinterpret_cast<const half4*>(Vh + G::VPLANE + off + 32);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { vh[e] = vh0[e]; vh[4 + e] = vh1[e]; vl[e] = vl0[e]; vl[4 + e] = vl1[e]; }
 #pragma unroll
@@ -312,90 +282,60 @@ void attention_f16x3_kernel(const float* __restrict__ qkv, const _Float16* __res
         }
     }
 
-    // O^T accumulator: col = query l16, row = d = 16t + 4kq + r
+    // O^T accumulator: col = query l16, row = d = 16t + 4kq + r.  Partials (m, l, unnormalised O^T x 2^14) of this split;
+    // the output projection combines the splits (conv1x1_f16x3.hip, ATT_PART_IN), also when there is only one.
 #pragma unroll
     for (int qm = 0; qm < QM; ++qm) {
         l[qm] *= (1.0f / A16_P_SCALE);                        // exact: back to the unscaled row sum
         const int qi = q0 + qm * 16 + l16;
         if (qi >= N) continue;
-        if (ksplit == 1) {
-            const float inv = 1.0f / (l[qm] * A16_QKV_SCALE * A16_P_SCALE);
-            float* orow = out + ((size_t)b * N + qi) * C + head * D + kq * 4;
+        float* orow = part_o + (((size_t)ks * gridDim.z + b) * N + qi) * C + head * D + kq * 4;
 #pragma unroll
-            for (int tt = 0; tt < DT; ++tt) *reinterpret_cast<f32x4*>(orow + tt * 16) = o[qm][tt] * inv;
-        } else {
-            float* orow = part_o + (((size_t)ks * gridDim.z + b) * N + qi) * C + head * D + kq * 4;
-#pragma unroll
-            for (int tt = 0; tt < DT; ++tt) *reinterpret_cast<f32x4*>(orow + tt * 16) = o[qm][tt];
-            if (kq == 0) {
-                float* ml = part_ml + ((((size_t)ks * gridDim.z + b) * heads + head) * N + qi) * 2;
-                ml[0] = m[qm]; ml[1] = l[qm];
-            }
+        for (int tt = 0; tt < DT; ++tt) *reinterpret_cast<f32x4*>(orow + tt * 16) = o[qm][tt];
+        if (kq == 0) {
+            float* ml = part_ml + ((((size_t)ks * gridDim.z + b) * heads + head) * N + qi) * 2;
+            ml[0] = m[qm]; ml[1] = l[qm];
         }
     }
 }
 
-// out[b][q][head*D + d] = sum_s O_s 2^(m_s - M) / (sum_s l_s 2^(m_s - M)) / (2^4 * 2^10), M = max_s m_s; splits in order.
-__global__ __launch_bounds__(256)
-void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out,
-                              int B, int N, int C, int D, int heads, int ksplit) {
-    const int CQ = C >> 2;
-    const size_t total = (size_t)B * N * CQ;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cq = (int)(idx % CQ);
-    const size_t bq = idx / CQ;                       // b * N + q
-    const int q = (int)(bq % N), b = (int)(bq / N);
-    const int head = (cq * 4) / D;
-    float mv[A16_MAX_SPLIT], lv[A16_MAX_SPLIT];
-    float M = -INFINITY;
-    for (int s = 0; s < ksplit; ++s) {
-        const float* ml = part_ml + ((((size_t)s * B + b) * heads + head) * N + q) * 2;
-        mv[s] = ml[0]; lv[s] = ml[1];
-        M = fmaxf(M, mv[s]);
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float L = 0.f;
-    for (int s = 0; s < ksplit; ++s) {
-        const float w = __builtin_amdgcn_exp2f(mv[s] - M);
-        L += lv[s] * w;
-        acc += *reinterpret_cast<const f32x4*>(part_o + (((size_t)s * B + b) * N + q) * C + cq * 4) * w;
-    }
-    *reinterpret_cast<f32x4*>(out + bq * C + cq * 4) = acc * (1.0f / (L * A16_QKV_SCALE * A16_P_SCALE));
-}
-
 static int att16_npad(int N) { return ((N + 63) / 64) * 64; }
 
-size_t attention16_scratch_bytes(int B, int N, int C) {
-    const size_t npad = (size_t)att16_npad(N);
-    const size_t kv = 2 * ((size_t)B * 2 * npad * C * sizeof(_Float16) + 256);                       // Kp + Vp (C = heads*D)
-    const size_t part = (size_t)A16_MAX_SPLIT * B * ((size_t)N * C + 2 * (size_t)N * 2) * sizeof(float) + 512;   // split partials (2 heads)
-    return kv + part;
+Att16Layout attention16_layout(int B, int N, int C) {
+    Att16Layout L{};
+    L.npad = att16_npad(N);
+    const size_t kbytes = (((size_t)B * 2 * L.npad * C * sizeof(_Float16)) + 255) & ~(size_t)255;       // K (and V): [B][heads][2][Npad][D], C = heads * D
+    const size_t pobytes = (((size_t)A16_MAX_SPLIT * B * N * C * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t mlbytes = (((size_t)A16_MAX_SPLIT * B * 2 * N * 2 * sizeof(float)) + 255) & ~(size_t)255;   // 2 heads x (m, l)
+    L.k_off = 0; L.v_off = kbytes; L.po_off = 2 * kbytes; L.ml_off = L.po_off + pobytes; L.bytes = L.ml_off + mlbytes;
+    return L;
 }
 
-hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int split_B, int N, int C, int heads, hipStream_t s) {
-    const int D = C / heads;
-    if (C % heads || !attention_supported(D) || D % 32 || heads != 2) return hipErrorInvalidValue;
-    const float qscale = (float)((1.0 / sqrt((double)D)) * 1.4426950408889634);
-    const int Npad = att16_npad(N);
-    char* sp = reinterpret_cast<char*>(scratch);
-    const size_t kbytes = (((size_t)B * 2 * Npad * C * sizeof(_Float16)) + 255) & ~(size_t)255;
-    _Float16* Kp = reinterpret_cast<_Float16*>(sp);
-    _Float16* Vp = reinterpret_cast<_Float16*>(sp + kbytes);
-    float* part_o = reinterpret_cast<float*>(sp + 2 * kbytes);
-    float* part_ml = part_o + (size_t)A16_MAX_SPLIT * B * N * C;
-    hipLaunchKernelGGL(attention_prep_kernel, dim3(Npad / 32, heads, B), dim3(256), 0, s, qkv, Kp, Vp, N, Npad, C, D, heads);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // Split the keys (flash-decoding) for occupancy: up to two workgroups per CU (what the LDS allows) while a split keeps
-    // >= 16 tiles of 32 keys (N = 4096: 375 -> 326 us per attention block), then up to one per CU down to two tiles per
-    // split (a 512 target with short splits measured slower at N = 1024).
+// Key split (flash-decoding) for occupancy: up to two workgroups per CU (what the LDS allows) while a split keeps
+// >= 16 tiles of 32 keys (N = 4096: 375 -> 326 us per attention block), then up to one per CU down to two tiles per
+// split (a 512 target with short splits measured slower at N = 1024).  The doubling loops only give a target: the
+// split count is then SHRUNK to the splits that own at least one tile (ceil(tiles / tiles_per_split)) -- e.g.
+// N = 784 (224x224 / 8): 25 tiles, target 8 -> 4 tiles per split -> 7 splits (round 2 returned an error there).
+void attention16_split(int N, int heads, int split_B, int* ksplit_out, int* tiles_per_split) {
     const int qblocks = (N + A16_QB - 1) / A16_QB, tiles = (N + A16_KT - 1) / A16_KT;
     int ksplit = 1;
     while ((long)qblocks * heads * split_B * ksplit < 512 && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 16) ksplit *= 2;
     while ((long)qblocks * heads * split_B * ksplit < 256 && ksplit * 2 <= A16_MAX_SPLIT && tiles / (ksplit * 2) >= 2) ksplit *= 2;
     const int tps = (tiles + ksplit - 1) / ksplit;
-    if ((long)(ksplit - 1) * tps >= tiles) return hipErrorInvalidValue;        // every split owns at least one tile that starts below N
+    ksplit = (tiles + tps - 1) / tps;               // every split owns >= 1 tile, and every tile starts below N
+    *ksplit_out = ksplit; *tiles_per_split = tps;
+}
+
+hipError_t attention16_launch(const float* q, const _Float16* Kp, const _Float16* Vp, float* part_o, float* part_ml,
+                              int B, int ksplit, int tps, int N, int C, int heads, hipStream_t s) {
+    const int D = C / heads;
+    if (C % heads || !attention_supported(D) || D % 32 || heads != 2) return hipErrorInvalidValue;
+    const int tiles = (N + A16_KT - 1) / A16_KT;
+    if (ksplit < 1 || ksplit > A16_MAX_SPLIT || tps < 1 || (long)(ksplit - 1) * tps >= tiles || (long)ksplit * tps < tiles) return hipErrorInvalidValue;
+    const float qscale = (float)((1.0 / sqrt((double)D)) * 1.4426950408889634);
+    const int Npad = att16_npad(N);
+    const int qblocks = (N + A16_QB - 1) / A16_QB;
+    hipError_t e = hipSuccess;
 #define MIDD_ATT(DD)                                                                                                        \
     {                                                                                                                       \
         constexpr int lds_bytes = 2 * Att16Geom<DD>::STAGE;                                                                 \
@@ -407,7 +347,7 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
             raised = true;                                                                                                  \
         }                                                                                                                   \
         hipLaunchKernelGGL((attention_f16x3_kernel<DD>), dim3(qblocks * ksplit, heads, B), dim3(256), lds_bytes, s,         \
-                           qkv, Kp, Vp, out, part_o, part_ml, N, Npad, C, qscale, ksplit, tps);                             \
+                           q, Kp, Vp, part_o, part_ml, N, Npad, C, qscale, ksplit, tps);                                    \
     }
     switch (D) {
         case 32:  MIDD_ATT(32) break;
@@ -416,11 +356,6 @@ hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B
         case 128: MIDD_ATT(128) break;
     }
 #undef MIDD_ATT
-    e = hipGetLastError();
-    if (e != hipSuccess || ksplit == 1) return e;
-    const size_t total = (size_t)B * N * (C / 4);
-    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       part_o, part_ml, out, B, N, C, D, heads, ksplit);
     return hipGetLastError();
 }
 

@@ -13,10 +13,22 @@
 //   * has no barrier in the K loop; the activation loads run two K-steps ahead in registers, across tile borders.
 // Epilogue and contract are those of conv_mfma_f16x3.hip (bias / time embedding / residual, GroupNorm partial
 // sums of the output per (workgroup, wave) row).  Weight pack: pack_conv_f16x3 (midd_api.hip), 32 channels per step.
+//
+// Attention hand-off (round 3: the attention block is three launches, qkv -> attention -> proj; it was five):
+//   ATT_QKV_OUT  the qkv projection writes what the attention kernel stages instead of an fp32 [B][N][3C] tensor that a
+//                separate pass re-read and converted: q as fp32 [B][N][C], k and v as split-fp16 images
+//                [B][heads][hi|lo][Npad][D] (x 2^4; rows of keys >= N zeroed).  |k|, |v| >= 4094 cannot be represented:
+//                the status word gets MI_STATUS_FP16_RANGE (mi_status) instead of a silent inf;
+//   ATT_PART_IN  the output projection reads the attention kernel's key-split partials (m_s, l_s, O_s) directly: the splits
+//                are extra K steps over the same weights, and each loaded element is scaled by
+//                2^(m_s - M) / (L 2^14), M = max_s m_s, L = sum_s l_s 2^(m_s - M) -- the flash-decoding combine, in split
+//                order, applied where the operand is converted anyway (it was a kernel of its own that wrote a tensor).
 #include "f16x3_common.h"
 #include <cstdlib>
 
 namespace midd {
+
+constexpr int C1_MAX_SPLIT = 8;                  // == A16_MAX_SPLIT (attention_f16x3.hip)
 
 template <int MT, int NT>
 struct Conv1Geom {
@@ -25,11 +37,14 @@ struct Conv1Geom {
     static constexpr int WSTEP = NT * 2048;                  // bytes of one K-step's weights (hi + lo, NT cout tiles)
     static constexpr int STAT_FLOATS = NW * 2 * NT * 16;
     static constexpr int ADD_FLOATS = NT * 16;
+    static constexpr int COEF_FLOATS = C1_MAX_SPLIT * 2 * BM;     // ATT_PART_IN: [split][head][pixel of the tile]
     static int weight_bytes(int cin) { const int w = ((cin + 31) / 32) * WSTEP; return w < 4096 ? 4096 : w; }      // also the statistics scratch at the end
-    static int lds_bytes(int cin) { return weight_bytes(cin) + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64; }
+    static int lds_bytes(int cin, int att_mode) {
+        return weight_bytes(cin) + (STAT_FLOATS + ADD_FLOATS) * 4 + 2 * cin * 4 + 64 + (att_mode == ATT_PART_IN ? COEF_FLOATS * 4 : 0);
+    }
 };
 
-template <int MT, int NT>
+template <int MT, int NT, int ATT>
 __global__ __launch_bounds__(256, 3)
 void conv1x1_f16x3_kernel(const ConvArgs a) {
     using G = Conv1Geom<MT, NT>;
@@ -43,7 +58,8 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     const int kq = lane >> 4;
 
     const int Cin = a.C0 + a.C1;
-    const int nsteps = (Cin + 31) >> 5;
+    const int csteps = (Cin + 31) >> 5;                       // K steps over the channels
+    const int nsteps = (ATT == ATT_PART_IN) ? csteps * a.att_ksplit : csteps;      // ... times the key splits
     const int HW = a.OH * a.OW;
     const int tiles = a.tiles_x;                              // ceil(HW / BM)
     const int b = blockIdx.x / a.wgs_per_img;
@@ -53,18 +69,25 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     const int ntile_wg = blockIdx.y * NT;
 
     char* const wl = lds;                                                        // [step][NT][hi|lo][lane] x 16 B
-    float* const stat_lds = reinterpret_cast<float*>(wl + max(nsteps * WSTEP, 4096));       // [wave][2][NT*16]  (Conv1Geom::weight_bytes)
+    float* const stat_lds = reinterpret_cast<float*>(wl + max(csteps * WSTEP, 4096));       // [wave][2][NT*16]  (Conv1Geom::weight_bytes)
     float* const add_lds = stat_lds + G::STAT_FLOATS;                            // [NT*16]
     float* const gnp = add_lds + G::ADD_FLOATS;                                  // [2][Cin] scale, shift
+    float* const coef_lds = gnp + 2 * Cin + 16;                                  // ATT_PART_IN: [split][head][BM]
 
     // ---- activation operand: registers, two K-steps ahead -------------------------------------
     // sequence s = 0 .. my_tiles*nsteps-1 walks (tile, step); each lane loads 8 channels of MT pixels per s
     const size_t img0 = (size_t)b * HW;
     auto load_a = [&](int tile, int step, f32x4 (&r)[MT][2]) {
-        int ch = step * 32 + kq * 8;
-        if (ch >= Cin) ch = Cin - 8;                          // trailing half step: valid dummy, zeroed in transform
         const float* src; int cs;
-        if (ch < a.C0) { src = a.src0 + ch; cs = a.C0; } else { src = a.src1 + (ch - a.C0); cs = a.C1; }
+        if constexpr (ATT == ATT_PART_IN) {
+            const int sp = step / csteps, cstep = step - sp * csteps;            // split-major: all channels of split 0, then split 1, ...
+            src = a.src0 + (size_t)sp * a.B * HW * Cin + cstep * 32 + kq * 8;
+            cs = Cin;
+        } else {
+            int ch = step * 32 + kq * 8;
+            if (ch >= Cin) ch = Cin - 8;                      // trailing half step: valid dummy, zeroed in transform
+            if (ch < a.C0) { src = a.src0 + ch; cs = a.C0; } else { src = a.src1 + (ch - a.C0); cs = a.C1; }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = min(tile * BM + (wave * MT + mt) * 16 + p16, HW - 1);
@@ -84,14 +107,18 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     {
         const char* wbase = reinterpret_cast<const char*>(a.wpack) + (size_t)ntile_wg * 2048 + lane * 16;
         const size_t wstep_bytes = (size_t)ntiles_total * 2048;
-        const int pieces = nsteps * NT * 2;                   // 1 KiB each
+        const int pieces = csteps * NT * 2;                   // 1 KiB each
         for (int piece = wave; piece < pieces; piece += G::NW) {
             const int step = piece / (NT * 2), r = piece - step * (NT * 2);
             dma16(wbase + step * wstep_bytes + r * 1024, wl + piece * 1024);
         }
     }
     if (a.prologue != PRO_RAW)            // GroupNorm scale / shift of this sample, the 2^s prescale folded in (exact)
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, ACT_PRESCALE, gnp, tid, G::NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, ACT_PRESCALE, gnp, tid, G::NTHREADS, a.status);
+    // raw operand with statistics of its own: power-of-two prescale from its sum of squares (stats_common.h)
+    stat_word* const raw_acc = reinterpret_cast<stat_word*>(gnp);
+    if (a.prologue == PRO_RAW && a.gn_tot0 != nullptr && wave == 0)
+        raw_sumsq_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, b, raw_acc, lane);
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
         for (int i = tid; i < G::ADD_FLOATS; i += G::NTHREADS) {
@@ -102,6 +129,16 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    float rscale = a.raw_scale_fixed, oscale = a.out_scale;
+    if (a.prologue == PRO_RAW) {
+        if (a.gn_tot0 != nullptr) {
+            bool bad;
+            const int ex = __builtin_amdgcn_readfirstlane(raw_prescale_exp(raw_acc, &bad));
+            rscale = pow2f(ex);
+            if (bad && tid == 0 && a.status != nullptr) atomicOr(a.status, (int)STATUS_NONFINITE);
+        }
+        oscale = a.out_scale / rscale;       // power of two: exact
+    }
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -114,32 +151,92 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     f32x4 ssum[NT], ssq[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     auto epilogue = [&](int tile) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = (ntile0 + nt) * 16 + kq * 4;
             const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + nt * 16 + kq * 4);
+            if constexpr (ATT == ATT_QKV_OUT) {
+                // channel = part * C + head * D + d (part: q, k, v); a 16-channel tile never straddles a part or a head (D % 32 == 0)
+                const int C = a.att_heads * a.att_D;
+                const int co0 = (ntile0 + nt) * 16;                      // uniform
+                const int part = co0 / C, cc0 = co0 - part * C;
+                const int head = cc0 / a.att_D, d = cc0 - head * a.att_D + kq * 4;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int p = tile * BM + (wave * MT + mt) * 16 + p16;
-                if (p < HW) {
-                    const size_t o = (img0 + p) * a.Cout + co;
-                    f32x4 v = acc[mt][nt] * a.out_scale + add;
-                    if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-                    *reinterpret_cast<f32x4*>(a.out + o) = v;
-                    ssum[nt] += v; ssq[nt] += v * v;
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int p = tile * BM + (wave * MT + mt) * 16 + p16;
+                    f32x4 v = acc[mt][nt] * oscale + add;
+                    if (part == 0) {
+                        if (p < HW) *reinterpret_cast<f32x4*>(a.out + (img0 + p) * C + cc0 + kq * 4) = v;
+                    } else if (p < a.att_npad) {
+                        if (p >= HW) v = (f32x4){0.f, 0.f, 0.f, 0.f};    // rows of the padded image beyond the last key
+                        const float big = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        if (!(big < 65504.0f / ACT_PRESCALE) && a.status != nullptr) atomicOr(a.status, (int)STATUS_FP16_RANGE);    // (also NaN)
+                        unsigned h01, h23, l01, l23;
+                        split_pair(v[0] * ACT_PRESCALE, v[1] * ACT_PRESCALE, h01, l01);
+                        split_pair(v[2] * ACT_PRESCALE, v[3] * ACT_PRESCALE, h23, l23);
+                        _Float16* img = (part == 1 ? a.att_k : a.att_v) + ((size_t)(b * a.att_heads + head) * 2) * a.att_npad * a.att_D;
+                        *reinterpret_cast<u32x2*>(img + (size_t)p * a.att_D + d) = (u32x2){h01, h23};
+                        *reinterpret_cast<u32x2*>(img + (size_t)(a.att_npad + p) * a.att_D + d) = (u32x2){l01, l23};
+                    }
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int p = tile * BM + (wave * MT + mt) * 16 + p16;
+                    if (p < HW) {
+                        const size_t o = (img0 + p) * a.Cout + co;
+                        f32x4 v = acc[mt][nt] * oscale + add;
+                        if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+                        *reinterpret_cast<f32x4*>(a.out + o) = v;
+                        ssum[nt] += v; ssq[nt] += v * v;
+                    }
+                    acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
             }
+        }
+    };
+
+    // ATT_PART_IN: the combine coefficients of a tile, [split][head][pixel]: 2^4 * 2^(m_s - M) / (L * 2^14) -- the operand is
+    // 16 * att, like every other fixed-prescale operand.  Thread (pixel, head); splits in order.
+    auto tile_coef = [&](int tile) {
+        if constexpr (ATT == ATT_PART_IN) {
+            lds_barrier();                                         // every wave is done with the previous tile's table
+            const int heads = a.att_heads, ks = a.att_ksplit;
+            for (int i = tid; i < BM * heads; i += G::NTHREADS) {
+                const int head = i / BM, pix = i - head * BM;
+                const int p = min(tile * BM + pix, HW - 1);
+                // three passes over the splits' (m, l) pairs (L1 / L2 hits) instead of arrays: registers are what this kernel is short of
+                const float* ml0 = a.att_ml + (((size_t)b * heads + head) * HW + p) * 2;
+                const size_t ml_stride = (size_t)a.B * heads * HW * 2;
+                float M = -INFINITY;
+#pragma unroll 1
+                for (int sp = 0; sp < ks; ++sp) M = fmaxf(M, ml0[sp * ml_stride]);
+                float L = 0.f;
+#pragma unroll 1
+                for (int sp = 0; sp < ks; ++sp) L += ml0[sp * ml_stride + 1] * __builtin_amdgcn_exp2f(ml0[sp * ml_stride] - M);
+                // O_s carries 2^4 (v) * 2^10 (p); l_s is the plain row sum: att = sum_s O_s w_s / (L 2^14)
+                const float inv = rscale / (L * 16384.0f);
+#pragma unroll 1
+                for (int sp = 0; sp < ks; ++sp) coef_lds[(sp * heads + head) * BM + pix] = __builtin_amdgcn_exp2f(ml0[sp * ml_stride] - M) * inv;
+            }
+            lds_barrier();
         }
     };
 
     // ---- K loop: transform (registers) -> request the load two steps ahead -> MFMAs --------------
     int c_tile = first_tile, c_step = 0;
     auto compute = [&](f32x4 (&r)[MT][2], bool more) {
-        const int ch = c_step * 32 + kq * 8;
+        int cstep = c_step, sp = 0;
+        if constexpr (ATT == ATT_PART_IN) {
+            if (c_step == 0) tile_coef(c_tile);
+            sp = c_step / csteps; cstep = c_step - sp * csteps;
+        }
+        const int ch = cstep * 32 + kq * 8;
         const bool valid = ch < Cin;
-        f32x4 sc0 = {RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE}, sc1 = sc0;     // raw operands: unscaled (see conv_mfma_f16x3.hip)
+        f32x4 sc0 = {rscale, rscale, rscale, rscale}, sc1 = sc0;     // raw operands: per-sample 2^a, or the fixed prescale (see conv_mfma_f16x3.hip)
         f32x4 sh0 = {0.f, 0.f, 0.f, 0.f}, sh1 = sh0;
         if (a.prologue != PRO_RAW && valid) {
             sc0 = *reinterpret_cast<const f32x4*>(gnp + ch);       sc1 = *reinterpret_cast<const f32x4*>(gnp + ch + 4);
@@ -148,7 +245,13 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         half8 xh[MT], xl[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            f32x4 v0 = r[mt][0] * sc0 + sh0, v1 = r[mt][1] * sc1 + sh1;
+            f32x4 v0, v1;
+            if constexpr (ATT == ATT_PART_IN) {
+                const float cf = coef_lds[(sp * a.att_heads + ch / a.att_D) * BM + (wave * MT + mt) * 16 + p16];
+                v0 = r[mt][0] * cf; v1 = r[mt][1] * cf;
+            } else {
+                v0 = r[mt][0] * sc0 + sh0; v1 = r[mt][1] * sc1 + sh1;
+            }
             if (a.prologue == PRO_GN_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {          // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
@@ -157,15 +260,18 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
                 }
             }
             if (!valid) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }     // channels past Cin meet zero weights; keep them finite
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const _Float16 h0 = (_Float16)v0[e], h1 = (_Float16)v1[e];
-                xh[mt][e] = h0;     xl[mt][e] = (_Float16)(v0[e] - (float)h0);
-                xh[mt][4 + e] = h1; xl[mt][4 + e] = (_Float16)(v1[e] - (float)h1);
-            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 hw, lw;
+            unsigned hh, ll;
+            split_pair(v0[0], v0[1], hh, ll); hw[0] = hh; lw[0] = ll;
+            split_pair(v0[2], v0[3], hh, ll); hw[1] = hh; lw[1] = ll;
+            split_pair(v1[0], v1[1], hh, ll); hw[2] = hh; lw[2] = ll;
+            split_pair(v1[2], v1[3], hh, ll); hw[3] = hh; lw[3] = ll;
+            xh[mt] = __builtin_bit_cast(half8, hw);
+            xl[mt] = __builtin_bit_cast(half8, lw);
         }
         if (more) { load_a(pf_tile, pf_step, r); advance(pf_tile, pf_step); }   // r is consumed: refill it for s + 2
-        const char* wslot = wl + c_step * WSTEP + lane * 16;
+        const char* wslot = wl + cstep * WSTEP + lane * 16;
         half8 wh[NT], wlo[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -223,7 +329,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int ATT>
 static hipError_t launch1(const ConvArgs& a0, hipStream_t s) {
     using G = Conv1Geom<MT, NT>;
     ConvArgs a = a0;
@@ -232,18 +338,18 @@ static hipError_t launch1(const ConvArgs& a0, hipStream_t s) {
     a.tiles_y = 1;
     const int ny = a.Cout / (NT * 16);
     a.wgs_per_img = conv16_wgs_per_img(a.tiles_x, a.B, ny, a.persist_wgs);
-    const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
+    const int lds_bytes = G::lds_bytes(a.C0 + a.C1, ATT);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (lds_bytes > 64 * 1024) {
         static int raised = 0;               // per instantiation
         if (lds_bytes > raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f16x3_kernel<MT, NT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f16x3_kernel<MT, NT, ATT>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
             if (e != hipSuccess) return e;
             raised = lds_bytes;
         }
     }
-    hipLaunchKernelGGL((conv1x1_f16x3_kernel<MT, NT>), dim3(a.B * a.wgs_per_img, ny), dim3(G::NTHREADS), lds_bytes, s, a);
+    hipLaunchKernelGGL((conv1x1_f16x3_kernel<MT, NT, ATT>), dim3(a.B * a.wgs_per_img, ny), dim3(G::NTHREADS), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -253,14 +359,25 @@ bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t) {
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const long wgs2 = (long)B * ((OH * OW + 127) / 128) * (Cout / (16 * nt));
     const int mt = wgs2 >= 512 ? 2 : 1;                      // small maps: 64-pixel tiles, twice the workgroups
-    if (((Cin + 31) / 32) * nt * 2048 + 8 * Cin + 4096 > 150 * 1024) return false;   // all weights must fit in LDS
+    if (((Cin + 31) / 32) * nt * 2048 + 8 * Cin + 4096 + 8192 > 150 * 1024) return false;   // all weights must fit in LDS
     *t = ConvTile{1, 1, 0, mt, nt, 4, 1};
     return true;
 }
 
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (a.C0 % 8 || a.C1 % 8) return hipErrorInvalidValue;  // an 8-channel lane group must not straddle the concat seam
-#define X(mt_, nt_) if (t.mt == mt_ && t.nt == nt_) return launch1<mt_, nt_>(a, s);
+    if (a.att_mode != ATT_NONE) {
+        // the hand-off's geometry: heads x D channels, D a multiple of 32 (a K step / a 16-channel tile stays inside one head)
+        if (a.att_D % 32 || a.att_heads != 2 || a.att_ksplit > C1_MAX_SPLIT) return hipErrorInvalidValue;
+        if (a.att_mode == ATT_PART_IN && (a.C1 != 0 || a.C0 != a.att_heads * a.att_D || a.prologue != PRO_RAW || a.gn_tot0 != nullptr)) return hipErrorInvalidValue;
+        if (a.att_mode == ATT_QKV_OUT && (a.Cout != 3 * a.att_heads * a.att_D || a.resid != nullptr || a.stat_tot != nullptr)) return hipErrorInvalidValue;
+    }
+#define X(mt_, nt_)                                                                       \
+    if (t.mt == mt_ && t.nt == nt_) {                                                     \
+        if (a.att_mode == ATT_QKV_OUT) return launch1<mt_, nt_, ATT_QKV_OUT>(a, s);       \
+        if (a.att_mode == ATT_PART_IN) return launch1<mt_, nt_, ATT_PART_IN>(a, s);       \
+        return launch1<mt_, nt_, ATT_NONE>(a, s);                                         \
+    }
     X(2, 3) X(1, 3) X(2, 2) X(1, 2) X(2, 1) X(1, 1)
 #undef X
     return hipErrorInvalidValue;

@@ -180,8 +180,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int q8 = tid % QPP;                             // (NTHREADS % QPP == 0: constant per thread)
     const int sblk = q8 >> 2;
     int g_off[APW];            // pixel index into the image; -1: out of the image; -2: slot beyond the tile
+    bool tile_pad = true;      // (uniform) the tile's halo leaves the image somewhere: only then a slot can be out of the image
     auto set_tile = [&](int t) {
         const int iy0 = (t / a.tiles_x) * TH * STRIDE - PAD, ix0 = (t % a.tiles_x) * TW * STRIDE - PAD;
+        tile_pad = iy0 < 0 || ix0 < 0 || iy0 + G::IH > a.H || ix0 + IW > a.W;
 #pragma unroll
         for (int s = 0; s < APW; ++s) {
             const int slot = tid + s * NTHREADS;
@@ -215,45 +217,68 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // write into the MFMA image.  (Measured in round 2: running the arithmetic of chunk c+1's transform under the MFMAs
     // of chunk c's steps 2..4 and only the LDS writes at the chunk boundary is 2-4 % SLOWER end to end -- the waves
     // reach the step barriers out of phase.)
+    float rscale = RAW_PRESCALE;          // 2^a of a raw operand (set after the prologue's barrier)
+    // The transform of a chunk, per slot: raw fp32 quad -> GroupNorm-apply (+SiLU) -> 2^s prescale -> hi/lo split -> MFMA image.
+    // Instruction diet of round 3 (the vector ALU is what a chunk costs beside its MFMAs):
+    //   * all raw quads of the chunk are requested before the first is used (one LDS round trip, not APW);
+    //   * SiLU on the exponent's own argument: the prologue leaves sc' = -log2(e) rstd gamma, sh' = -log2(e) (beta - mean rstd gamma),
+    //     so t = x sc' + sh' = -y log2(e) feeds v_exp directly, d = (1 + 2^t) / 16 is ONE fma, and the operand is
+    //     u = t / d = -16 log2(e) silu(y); the constant -ln 2 that turns u back into 16 silu(y) sits in the packed
+    //     weights (pack_conv_f16x3: SILU_WEIGHT_FACTOR) -- 5 instructions per element instead of 6, 2 of them transcendental;
+    //   * hi = fp16(u) by v_cvt_pk_f16_f32, lo = fp16(u - hi) by ONE v_fma_mix per element (f16x3_common.h: split_pair);
+    //   * no select for the conv's zero padding: out-of-image slots are zeroed ONCE per tile (first chunk) and otherwise
+    //     simply not written (g_off < 0 also covers a thread's slot beyond the tile): the only conditional code is
+    //     the pair of LDS stores.
+    // (Measured in round 2: running the arithmetic of chunk c+1's transform under the MFMAs of chunk c's steps 2..4 and
+    // only the LDS writes at the chunk boundary is 2-4 % SLOWER end to end -- the waves reach the step barriers out of phase.)
     auto transform = [&](int c) {
         const int blk = CB * c + sblk;
         if (blk >= nblk) return;
         const int ch = (blk << 4) + (q8 & 3) * 4;
-        // y' = 2^s * act(x*sc + sh): the prescale is folded into the affine (exact, power of two)
-        // raw operands (stride-2, folded ConvT, res_conv: not bounded by a GroupNorm) are split unscaled, so the
-        // whole fp16 range (|x| < 65504) is available to them; normalised ones carry 2^s = 16
-        f32x4 sc = {RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE, RAW_PRESCALE}, sh = {0.f, 0.f, 0.f, 0.f};
+        f32x4 rq[APW];
+#pragma unroll
+        for (int s = 0; s < APW; ++s) rq[s] = *reinterpret_cast<const f32x4*>(raw + (tid + s * NTHREADS) * 16);
+        f32x4 sc = {rscale, rscale, rscale, rscale}, sh = {0.f, 0.f, 0.f, 0.f};      // raw operand: per-sample 2^a (stats_common.h)
         if (a.prologue != PRO_RAW) {
-            sc = *reinterpret_cast<const f32x4*>(gnp + ch) * ACT_PRESCALE;
-            sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch) * ACT_PRESCALE;
+            sc = *reinterpret_cast<const f32x4*>(gnp + ch);
+            sh = *reinterpret_cast<const f32x4*>(gnp + Cin + ch);
         }
         char* base = img + sblk * 2 * PLANE + (q8 & 3) * 8;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if (c == 0 && tile_pad) {                  // (uniform) first chunk of a tile whose halo leaves the image: the conv's zero padding
+#pragma unroll
+            for (int s = 0; s < APW; ++s) {
+                const int slot = tid + s * NTHREADS;
+                if (g_off[s] == -1) {                  // (a thread's slots cover ITS 16-channel block: all blocks get zeroed between the threads)
+                    *reinterpret_cast<u32x2*>(base + (slot / QPP) * 32) = (u32x2){0u, 0u};
+                    *reinterpret_cast<u32x2*>(base + PLANE + (slot / QPP) * 32) = (u32x2){0u, 0u};
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < APW; ++s) {
             const int slot = tid + s * NTHREADS;
-            if (g_off[s] > -2) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(raw + slot * 16);
-                v = v * sc + sh;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rq[s][e], sc[e], sh[e]);
 #if defined(C16_ABL) && C16_ABL == 4     // ablation 4 (wrong results): no SiLU
-                if (false) {
+            if (false) {
 #else
-                if (a.prologue == PRO_GN_SILU) {
+            if (a.prologue == PRO_GN_SILU) {
 #endif
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)      // v = 16*y: silu -> v * 1/(1 + 2^(-y*log2 e))
-                        v[e] = v[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v[e] * (-1.4426950408889634f / ACT_PRESCALE)));
+                for (int e = 0; e < 4; ++e) {      // v = t = -y log2(e):  u = t * 16 / (1 + 2^t)
+                    const float d = __builtin_fmaf(__builtin_amdgcn_exp2f(v[e]), 1.0f / ACT_PRESCALE, 1.0f / ACT_PRESCALE);
+                    v[e] = v[e] * __builtin_amdgcn_rcpf(d);
                 }
-                if (g_off[s] < 0) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // the conv pads its (normalised) input with zeros
-                half4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const _Float16 h = (_Float16)v[e];
-                    hi[e] = h;
-                    lo[e] = (_Float16)(v[e] - (float)h);
-                }
+            }
+            unsigned h01, h23, l01, l23;
+            split_pair(v[0], v[1], h01, l01);
+            split_pair(v[2], v[3], h23, l23);
+            if (g_off[s] >= 0) {                   // in the image and in the tile
                 const int pix = slot / QPP;
-                *reinterpret_cast<half4*>(base + pix * 32) = hi;
-                *reinterpret_cast<half4*>(base + PLANE + pix * 32) = lo;
+                *reinterpret_cast<u32x2*>(base + pix * 32) = (u32x2){h01, h23};
+                *reinterpret_cast<u32x2*>(base + PLANE + pix * 32) = (u32x2){l01, l23};
             }
         }
     };
@@ -297,8 +322,14 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // wait, so that the GroupNorm arithmetic overlaps the DMA latency instead of following it -- 0 % split, -0.7 % unsplit.)
 #if !(defined(C16_ABL) && C16_ABL == 6)  // ablation 6 (wrong results): no GroupNorm prologue
     if (a.prologue == PRO_GN || a.prologue == PRO_GN_SILU)       // GroupNorm scale / shift of this sample (stats_common.h)
-        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b, 1.0f, gnp, tid, NTHREADS);
+        gn_prologue_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, a.gn_inv_n, b,
+                        (a.prologue == PRO_GN_SILU) ? SILU_ARG_FACTOR : ACT_PRESCALE, gnp, tid, NTHREADS, a.status);
 #endif
+    // raw operand: its sum of squares from the producers' totals -> power-of-two prescale (stats_common.h); the scale /
+    // shift area is free in this case
+    stat_word* const raw_acc = reinterpret_cast<stat_word*>(gnp);
+    if (a.prologue == PRO_RAW && a.gn_tot0 != nullptr && wave == 0)
+        raw_sumsq_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, b, raw_acc, lane);
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
         for (int i = tid; i < G::ADD_FLOATS; i += NTHREADS) {
@@ -307,6 +338,17 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         }
     }
     wait_vm_and_barrier<0>();               // everything above has landed / is visible (once per launch)
+    float oscale = a.out_scale;             // epilogue factor: undoes the weight and the operand prescale (exact)
+    if (a.prologue == PRO_RAW) {
+        rscale = a.raw_scale_fixed;
+        if (a.gn_tot0 != nullptr) {
+            bool bad;
+            const int ex = __builtin_amdgcn_readfirstlane(raw_prescale_exp(raw_acc, &bad));
+            rscale = pow2f(ex);
+            if (bad && tid == 0 && a.status != nullptr) atomicOr(a.status, (int)STATUS_NONFINITE);
+        }
+        oscale = a.out_scale / rscale;      // power of two: exact
+    }
     transform(0);
     if constexpr (WM == 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -418,7 +460,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
-                    f32x4 v = acc[mt][nt] * a.out_scale + add;
+                    f32x4 v = acc[mt][nt] * oscale + add;
                     if (a.resid != nullptr) v += rres[nt];
                     *reinterpret_cast<f32x4*>(a.out + o + nt * 16) = v;
 #if !(defined(C16_ABL) && C16_ABL == 1)  // ablation 1 (wrong results): no statistics of the output

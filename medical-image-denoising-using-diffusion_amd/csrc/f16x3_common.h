@@ -9,7 +9,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 constexpr float ACT_PRESCALE = 16.0f;             // 2^s, s = 4, of GroupNorm-ed operands (see header); must match midd_api.hip
-constexpr float RAW_PRESCALE = 1.0f;              // operands no GroupNorm bounds keep fp16's full range: |x| < 65504
+// GroupNorm + SiLU operands of the 3x3 kernel: the transform forms t = -log2(e) y and u = 16 t / (1 + 2^t) = -16 log2(e) silu(y);
+// the packed weights of those convolutions carry the factor -ln 2 that makes w'' . u = 16 w . silu(y) (midd_api.hip).
+constexpr float SILU_ARG_FACTOR = -1.4426950408889634f;
+constexpr float SILU_WEIGHT_FACTOR = -0.6931471805599453f;
+constexpr float RAW_PRESCALE = 1.0f;              // raw operands without statistics of their own (none on the default networks)
+constexpr float ATT_PRESCALE = 16.0f;             // the attention output entering proj: |att| <= max|v| and 16 |v| < 65504 was checked
 
 __device__ __forceinline__ float silu16(float v) {
     // x * 1/(1+2^(-x*log2 e)) on v_exp_f32 / v_rcp_f32 (~1 ulp each)
@@ -34,6 +39,19 @@ __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
         hi[e] = h;
         lo[e] = (_Float16)(x - (float)h);
     }
+}
+
+// The two fp16 halves of a pair of fp32 values: hi = fp16(x) (round to nearest even: v_cvt_pk_f16_f32), lo = fp16(x - hi).
+// x - hi is exact in fp32 (hi is x rounded to 11 bits), and v_fma_mix{lo,hi}_f16 computes (-1) * hi + x in fp32 with hi
+// read as the fp16 it is and rounds the result to fp16 into one half of the destination: ONE instruction per element for
+// lo instead of convert-back, subtract, convert (checked bit for bit against the three-instruction form: tools/mb).
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 h;
+    h[0] = (_Float16)x0; h[1] = (_Float16)x1;
+    hi = __builtin_bit_cast(unsigned, h);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(x1));
 }
 
 // Wait until at most N of this wave's vector-memory operations (all of them LDS-DMA inside the

@@ -70,7 +70,8 @@ struct Op {
     TensorRef s0, s1, dst, resid;
     bool has_s1 = false, has_resid = false;
     GnRef gn;                   // OP_CONV / OP_OUT: GroupNorm of (s0, s1) applied while staging
-    size_t partial_off = 0;     // OP_ATTN: pre-split K / V^T scratch
+    size_t partial_off = 0;     // OP_ATTN and its two projections (f16x3): the attention scratch (attention16_layout)
+    int att_mode = ATT_NONE, att_ksplit = 1, att_tps = 1;      // f16x3 attention hand-off (conv1x1_f16x3.hip); key split of the block
     int stat_rows = 0;          // OP_CHAN_TOT: blocks per sample
     // OP_CONV
     size_t w = 0, b = 0;
@@ -78,6 +79,8 @@ struct Op {
     ConvTile tile{};
     int stride = 1, ks = 3;
     bool want_stats = false;
+    bool raw_stats = false;     // prologue RAW: the sources' totals exist -> per-sample power-of-two prescale (stats_common.h)
+    float raw_scale_fixed = 1.f; // prologue RAW without totals: fixed prescale of the operand
     float out_scale = 1.f;
 };
 
@@ -263,6 +266,17 @@ extern "C" int mi_image_metrics(const void* target, const void* pred, int n, int
 extern "C" const char* mi_last_error(void) { return g_err; }
 extern "C" const char* mi_version(void) { return "midd 0.4 gfx950 (fp32 MFMA | split-fp16 x3 MFMA; GroupNorm statistics in the producers; device pre/post-processing)"; }
 
+#ifndef MIDD_SOURCE_HASH
+#define MIDD_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* mi_source_hash(void) { return MIDD_SOURCE_HASH; }
+
+extern "C" int mi_debug_attention_split(int N, int B, int* ksplit, int* tiles_per_split) {
+    if (N < 1 || B < 1 || !ksplit || !tiles_per_split) return fail(MI_EINVAL, "N and B must be positive");
+    attention16_split(N, ATTN_HEADS_ABI, B, ksplit, tiles_per_split);
+    return MI_OK;
+}
+
 extern "C" int mi_unet_plan_create(const mi_unet_cfg* cfg, mi_plan** out) {
     if (!cfg || !out) return fail(MI_EINVAL, "null argument");
     if (cfg->num_levels < 1 || cfg->num_levels > MI_MAX_LEVELS) return fail(MI_EINVAL, "num_levels out of range");
@@ -359,7 +373,17 @@ static std::vector<float> pack_conv_f32(const float* w, int Cout, int Cin, int K
 // w' = w * 2^k (k per layer, max|w'| in [2^13,2^14)); hi = fp16(w'), lo = fp16(w' - hi).
 // *out_scale = 2^-k / ACT_PRESCALE.  Returned as raw 32-bit words (two fp16 each).
 static const float ACT_PRESCALE_H = 16.0f;      // 2^s: must match ACT_PRESCALE in conv_mfma_f16x3.hip
-static std::vector<float> pack_conv_f16x3(const float* w, int Cout, int Cin, int KS, float* out_scale) {
+static const float SILU_WEIGHT_FACTOR_H = -0.6931471805599453f;     // == SILU_WEIGHT_FACTOR (f16x3_common.h): see conv_mfma_f16x3.hip, transform
+static std::vector<float> pack_conv_f16x3(const float* w_in, int Cout, int Cin, int KS, float* out_scale, float wmul = 1.0f) {
+    // wmul: constant folded into the weights (fp32 product, rounded once): -ln 2 for the convolutions behind GroupNorm + SiLU,
+    // whose operand the kernel forms as -16 log2(e) silu(y)
+    std::vector<float> wm;
+    const float* w = w_in;
+    if (wmul != 1.0f) {
+        wm.resize((size_t)Cout * Cin * KS * KS);
+        for (size_t i = 0; i < wm.size(); ++i) wm[i] = w_in[i] * wmul;
+        w = wm.data();
+    }
     const int taps = KS * KS, nblk = Cin / 16, ntile = Cout / 16;
     const int steps = conv16_num_steps(Cin, taps);
     float wmax = 0.f;
@@ -484,9 +508,9 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
 
     Packer pk;
     const bool f16 = plan->cfg.compute_mode == MI_COMPUTE_F16X3;
-    auto pack_conv = [&](const float* w, int Cout, int Cin, int KS, float* scale) {
+    auto pack_conv = [&](const float* w, int Cout, int Cin, int KS, float* scale, bool behind_silu = false) {
         *scale = 1.0f;
-        return f16 ? pack_conv_f16x3(w, Cout, Cin, KS, scale) : pack_conv_f32(w, Cout, Cin, KS);
+        return f16 ? pack_conv_f16x3(w, Cout, Cin, KS, scale, behind_silu ? SILU_WEIGHT_FACTOR_H : 1.0f) : pack_conv_f32(w, Cout, Cin, KS);
     };
     auto W = [&](const std::string& k) { return getw(plan, k)->data.data(); };
     auto put_raw = [&](const std::string& k) { return pk.put(getw(plan, k)->data); };
@@ -494,9 +518,9 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
         switch (m.kind) {
             case MOD_RB:
                 m.g1 = put_raw(m.name + ".block1.0.weight"); m.be1 = put_raw(m.name + ".block1.0.bias");
-                m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3, &m.s1)); m.b1 = put_raw(m.name + ".block1.2.bias");
+                m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3, &m.s1, true)); m.b1 = put_raw(m.name + ".block1.2.bias");
                 m.g2 = put_raw(m.name + ".block2.0.weight"); m.be2 = put_raw(m.name + ".block2.0.bias");
-                m.w2 = pk.put(pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3, &m.s2)); m.b2 = put_raw(m.name + ".block2.3.bias");
+                m.w2 = pk.put(pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3, &m.s2, true)); m.b2 = put_raw(m.name + ".block2.3.bias");
                 if (m.in_c != m.out_c) {
                     m.wr = pk.put(pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1, &m.sr)); m.br = put_raw(m.name + ".res_conv.bias");
                 }
@@ -596,10 +620,14 @@ struct Builder {
         Op o{}; o.kind = OP_CHAN_TOT; o.s0 = t; o.stat_rows = chan_partial_rows(t.H * t.W, t.C); g->ops.push_back(o);
     }
     int conv(const TensorRef& s0, const TensorRef* s1, TensorRef& dst, size_t w, size_t b, float wscale, int ks, int stride,
-             int prologue, GnRef gn, int temb_col, const TensorRef* resid, bool want_stats) {
-        Op o{}; o.kind = OP_CONV; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
-        // wscale = 2^-k / 2^s undoes the weight and the activation prescale; raw operands are not prescaled
+             int prologue, GnRef gn, int temb_col, const TensorRef* resid, bool want_stats, float raw_scale_fixed = 1.0f,
+             int att_mode = ATT_NONE, size_t att_scratch = 0, int att_ksplit = 1) {
+        Op o{}; o.kind = OP_CONV; o.att_mode = att_mode; o.partial_off = att_scratch; o.att_ksplit = att_ksplit; o.s0 = s0; if (s1) { o.s1 = *s1; o.has_s1 = true; }
+        // wscale = 2^-k / 2^s undoes the weight and the activation prescale; a raw operand's own prescale (per sample from
+        // its statistics, or raw_scale_fixed) is divided out inside the kernel
         o.out_scale = (prologue == PRO_RAW && p->cfg.compute_mode == MI_COMPUTE_F16X3) ? wscale * ACT_PRESCALE_H : wscale;
+        o.raw_scale_fixed = raw_scale_fixed;
+        o.raw_stats = prologue == PRO_RAW && s0.stat_id >= 0 && (!s1 || s1->stat_id >= 0);
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col; o.gn = gn;
         if (gn.on) { if (int rcg = gn_consumer(s0, s1)) return rcg; }
         if (resid) { o.resid = *resid; o.has_resid = true; }
@@ -626,6 +654,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     if (g->stat_rep < 1) g->stat_rep = 1;
     if (g->stat_rep > STAT_MAX_REPLICAS) g->stat_rep = STAT_MAX_REPLICAS;
     Builder bld{p, g, Bump{}, B};
+    (void)bld.bump.take(256);                 // [0, 256): the call's status word (mi_status); sub-batch programs leave theirs unused
     g->trow_off = bld.bump.take((size_t)B * sizeof(int));
     int rc;
 
@@ -653,15 +682,33 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         return MI_OK;
     };
     auto run_attn = [&](const Mod& m, const TensorRef& x, TensorRef* out) -> int {
-        const int C = x.C;
-        TensorRef qkv = bld.alloc(3 * C, x.H, x.W);
-        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, GnRef{m.g1, m.be1, true}, -1, nullptr, false))) return rc;
-        TensorRef att = bld.alloc(C, x.H, x.W);
-        Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = att;
-        o.partial_off = bld.bump.take(attention16_scratch_bytes(B, x.H * x.W, C));      // pre-split K / V^T (f16x3)
-        g->ops.push_back(o);
+        const int C = x.C, N = x.H * x.W;
+        const GnRef gnorm{m.g1, m.be1, true};
         TensorRef y = bld.alloc(C, x.H, x.W);
-        if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, m.sp, 1, 1, PRO_RAW, no_gn, -1, &x, true))) return rc;
+        if (p->cfg.compute_mode != MI_COMPUTE_F16X3) {         // fp32 MFMA mode: qkv tensor -> attention -> att tensor -> proj
+            TensorRef qkv = bld.alloc(3 * C, x.H, x.W);
+            if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, gnorm, -1, nullptr, false))) return rc;
+            TensorRef att = bld.alloc(C, x.H, x.W);
+            Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = att;
+            g->ops.push_back(o);
+            if ((rc = bld.conv(att, nullptr, y, m.wp, m.bp, m.sp, 1, 1, PRO_RAW, no_gn, -1, &x, true))) return rc;
+            *out = y;
+            return MI_OK;
+        }
+        // split-fp16 mode, three launches: the qkv projection's epilogue writes q (fp32 [B][N][C], the head of `qkv`'s buffer)
+        // and the split-fp16 K / V images into the scratch; the attention kernel leaves key-split partials there; the
+        // output projection combines them while it loads its operand
+        const Att16Layout lay = attention16_layout(B, N, C);
+        const size_t scratch = bld.bump.take(lay.bytes);
+        int ksplit = 1, tps = 1;
+        attention16_split(N, ATTN_HEADS_ABI, p->batch_invariant ? 1 : B, &ksplit, &tps);
+        TensorRef qkv = bld.alloc(3 * C, x.H, x.W);            // Cout of the projection; only [B][N][C] floats (q) are written
+        if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, gnorm, -1, nullptr, false, 1.0f, ATT_QKV_OUT, scratch, ksplit))) return rc;
+        Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = y; o.partial_off = scratch; o.att_ksplit = ksplit; o.att_tps = tps;
+        g->ops.push_back(o);
+        TensorRef part{}; part.off = scratch + lay.po_off; part.C = C; part.H = x.H; part.W = x.W;      // split 0 of the partials: [ksplit][B][N][C]
+        // |att| <= max|v|, and 16 v is within fp16 (checked by the qkv epilogue): fixed prescale 2^4
+        if ((rc = bld.conv(part, nullptr, y, m.wp, m.bp, m.sp, 1, 1, PRO_RAW, no_gn, -1, &x, true, ACT_PRESCALE_H, ATT_PART_IN, scratch, ksplit))) return rc;
         *out = y;
         return MI_OK;
     };
@@ -807,7 +854,7 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
         case OP_CHAN_TOT: *name = "midd::chan_total_kernel"; *flops = 0; *bytes = 4.0 * elems(o.s0); break;
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
-                snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d>", o.tile.mt, o.tile.nt);
+                snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d, %d>", o.tile.mt, o.tile.nt, o.att_mode);
             else
                 snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
                          p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
@@ -840,7 +887,8 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
     }
 }
 
-static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipStream_t s,
+// status: the call's status word (first word of the CALLER's workspace, whichever sub-batch program runs)
+static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* status, hipStream_t s,
                        hipEvent_t mid_event = nullptr, int mid_div = 2) {
     const float* wd = p->wdev;
     auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
@@ -877,9 +925,19 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 a.B = B; a.H = o.s0.H; a.W = o.s0.W; a.OH = o.dst.H; a.OW = o.dst.W;
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue; a.stat_rep = g->stat_rep;
-                if (o.gn.on) {
+                a.raw_scale_fixed = o.raw_scale_fixed; a.status = status;
+                if (o.att_mode != ATT_NONE) {
+                    const Att16Layout lay = attention16_layout(B, o.dst.H * o.dst.W, o.att_mode == ATT_QKV_OUT ? o.dst.C / 3 : o.dst.C);
+                    a.att_mode = o.att_mode; a.att_heads = ATTN_HEADS_ABI; a.att_D = (o.att_mode == ATT_QKV_OUT ? o.dst.C / 3 : o.dst.C) / ATTN_HEADS_ABI;
+                    a.att_npad = lay.npad; a.att_ksplit = o.att_ksplit;
+                    a.att_k = reinterpret_cast<_Float16*>(ws + o.partial_off + lay.k_off); a.att_v = reinterpret_cast<_Float16*>(ws + o.partial_off + lay.v_off);
+                    a.att_ml = reinterpret_cast<const float*>(ws + o.partial_off + lay.ml_off);
+                }
+                if (o.gn.on || o.raw_stats) {
                     a.gn_tot0 = T(o.s0.tot_off); a.gn_bs0 = o.s0.stat_bs;
                     a.gn_tot1 = o.has_s1 ? T(o.s1.tot_off) : T(o.s0.tot_off); a.gn_bs1 = o.has_s1 ? o.s1.stat_bs : 1;
+                }
+                if (o.gn.on) {
                     a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                     a.gn_inv_n = 1.0 / ((double)o.s0.H * o.s0.W * ((a.C0 + a.C1) / GN_GROUPS_));
                 }
@@ -892,9 +950,16 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, hipSt
                 break;
             }
             case OP_ATTN:
-                e = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
-                        ? attention16_launch(F(o.s0.off), F(o.dst.off), ws + o.partial_off, B, p->batch_invariant ? 1 : B, o.dst.H * o.dst.W, o.dst.C, 2, s)
-                        : attention_launch(F(o.s0.off), F(o.dst.off), B, o.dst.H * o.dst.W, o.dst.C, 2, s);
+                if (p->cfg.compute_mode == MI_COMPUTE_F16X3) {
+                    const int N = o.dst.H * o.dst.W, C = o.dst.C;
+                    const Att16Layout lay = attention16_layout(B, N, C);
+                    char* sc = ws + o.partial_off;
+                    e = attention16_launch(F(o.s0.off), reinterpret_cast<const _Float16*>(sc + lay.k_off), reinterpret_cast<const _Float16*>(sc + lay.v_off),
+                                           reinterpret_cast<float*>(sc + lay.po_off), reinterpret_cast<float*>(sc + lay.ml_off),
+                                           B, o.att_ksplit, o.att_tps, N, C, ATTN_HEADS_ABI, s);
+                } else {
+                    e = attention_launch(F(o.s0.off), F(o.dst.off), B, o.dst.H * o.dst.W, o.dst.C, 2, s);
+                }
                 break;
             case OP_RESIZE:
                 e = resize_bilinear_launch(F(o.s0.off), F(o.dst.off), T(o.dst.tot_off), g->stat_rep, o.dst.stat_bs, B, o.s0.H, o.s0.W, o.s0.C, o.dst.H, o.dst.W, s);
@@ -955,10 +1020,11 @@ extern "C" int mi_unet_forward(mi_plan* plan, const float* x, const float* condi
         if (t[i] < 0 || t[i] >= plan->time_rows) return fail(MI_EINVAL, "timestep %d outside the precomputed table [0,%d)", t[i], plan->time_rows);
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
+    HIPCHK(hipMemsetAsync(ws, 0, 256, s));                  // status word
     hipError_t e = fill_i32_launch(reinterpret_cast<int*>(ws + g->trow_off), t, B, s);
     if (e != hipSuccess) return fail(MI_EHIP, "fill timesteps: %s", hipGetErrorString(e));
     StepIO io{x, condition, eps, nullptr, nullptr, 0.f, 0.f, 0.f, 0};
-    return run_program(plan, g, io, ws, s);
+    return run_program(plan, g, io, ws, reinterpret_cast<int*>(ws), s);
 }
 
 extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, int W,
@@ -985,6 +1051,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         *c2 = (1.0f - alpha[t]) / sqrtf(1.0f - alpha_hat[t]);
         *c3 = sqrtf(beta[t]);
     };
+    HIPCHK(hipMemsetAsync(ws, 0, 256, s));                  // status word (before the side streams fork)
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, s));   // x = noisy_img.clone()
     const int parts = split_parts(B);
     if (parts > 1 && n_iters > 0) {
@@ -1022,7 +1089,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
                     io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
                     if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
                     hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
-                    int rc2 = run_program(plan, gh, io, wsh, sh, mid, parts);
+                    int rc2 = run_program(plan, gh, io, wsh, reinterpret_cast<int*>(ws), sh, mid, parts);
                     if (rc2) return rc2;
                 }
             }
@@ -1047,8 +1114,19 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
         coef(t, &io.c1, &io.c2, &io.c3);
         io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems : nullptr;          // cddpmModels.py:297-300
         io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
-        if ((rc = run_program(plan, g, io, ws, s))) return rc;
+        if ((rc = run_program(plan, g, io, ws, reinterpret_cast<int*>(ws), s))) return rc;
     }
+    return MI_OK;
+}
+
+extern "C" int mi_status(const void* workspace, void* stream, int* flags) {
+    if (!workspace || !flags) return fail(MI_EINVAL, "null argument");
+    int host = 0;
+    HIPCHK(hipMemcpyAsync(&host, workspace, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    *flags = host;
+    if (host & MI_STATUS_NONFINITE) return fail(MI_ERANGE, "non-finite activations (NaN / Inf) reached a GroupNorm statistic or a raw operand");
+    if (host & MI_STATUS_FP16_RANGE) return fail(MI_ERANGE, "an attention operand exceeds the split-fp16 range (|q|, |k| or |v| >= 4094): use compute=\"f32\"");
     return MI_OK;
 }
 

@@ -23,8 +23,12 @@ struct ConvArgs {
     // GroupNorm of the INPUT (prologue != RAW): per-channel fixed-point (sum, sum of squares) totals of the two
     // concatenated sources, [B][C0/bs0][rep][2][3] / [B][C1/bs1][rep][2][3] limbs, accumulated by the producers (stats_common.h); every
     // workgroup derives scale = rstd*gamma, shift = beta - mean*rstd*gamma of its sample in its prologue
+    // prologue == RAW (f16x3 kernels): the same totals, when present, give the operand's power-of-two prescale
+    // (raw_prescale_exp, stats_common.h); gn_tot0 == null: the fixed prescale raw_scale_fixed
     const stat_word* gn_tot0; const stat_word* gn_tot1;
     int gn_bs0, gn_bs1;     // channels per totals block of each source (whole blocks per GroupNorm group)
+    float raw_scale_fixed;  // f16x3, prologue == RAW without totals: 2^s applied to the operand (out_scale undoes it)
+    int* status;            // device word of the workspace: bit MI_STATUS_* set when a kernel meets a non-finite statistic / an operand beyond fp16 (may be null)
     const float* gn_gamma; const float* gn_beta; float gn_eps; double gn_inv_n;      // affine [Cin], eps, 1 / (pixels * channels per group)
     int prologue;
     const float* temb;      // time table [rows][temb_stride], already offset to this block's column
@@ -38,6 +42,16 @@ struct ConvArgs {
     stat_word* stat_tot;
     int stat_rep;           // copies of every totals block of this program (stats_common.h), also for gn_tot0/1
     int stat_bs;            // channels per totals block of the OUTPUT
+    // attention hand-off of the f16x3 1x1 kernel (conv1x1_f16x3.hip; att_mode == ATT_NONE everywhere else)
+    //   ATT_QKV_OUT  (the qkv projection): q goes to `out` as fp32 [B][N][C]; k and v are written as the split-fp16 images
+    //                the attention kernel stages, att_k / att_v [B][heads][hi|lo][Npad][D] (x 2^4), keys >= N zeroed
+    //   ATT_PART_IN  (the output projection): the operand is the attention kernel's key-split partials,
+    //                src0 = part_o [ksplit][B][N][C] (unnormalised), att_ml [ksplit][B][heads][N][2] = (m, l); the splits
+    //                are extra K steps, each element scaled by 2^(m_s - M) / (L 2^14) of its (pixel, head, split) on load
+    int att_mode;
+    _Float16* att_k; _Float16* att_v;
+    const float* att_ml;
+    int att_heads, att_D, att_npad, att_ksplit;
     int tiles_x, tiles_y;
     int wgs_per_img;        // f16x3: persistent workgroups per sample (each walks tiles j, j+wgs_per_img, ...)
     int persist_wgs;        // f16x3: persistent-workgroup target of the launch (0 = default)
@@ -51,6 +65,8 @@ struct ConvTile {           // which template instance to launch
 };
 
 enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
+enum AttMode { ATT_NONE = 0, ATT_QKV_OUT = 1, ATT_PART_IN = 2 };
+enum StatusBits { STATUS_NONFINITE = 1, STATUS_FP16_RANGE = 2 };      // == MI_STATUS_* (include/midd.h)
 
 // Picks a tile for (Cout, output pixels, kernel size, stride); returns false if unsupported.
 bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
@@ -94,10 +110,16 @@ hipError_t metrics_launch(const float* target, const float* pred, int n, int h, 
 // ---------------------------------------------------------------- attention
 // qkv: NHWC [B][N][3C], channel = s*C + head*D + d (s in q,k,v);  out: [B][N][C]
 hipError_t attention_launch(const float* qkv, float* out, int B, int N, int C, int heads, hipStream_t s);
-// split-fp16 variant; `scratch` (attention16_scratch_bytes) holds the pre-split K and V^T images
+// split-fp16 variant (attention_f16x3.hip).  Three launches per attention block: the qkv projection's epilogue writes q (fp32
+// [B][N][C]) and the split-fp16 images of k and v, the attention kernel leaves key-split partials, the output projection
+// combines them while it loads its operand.  Scratch layout (attention16_layout): K image, V image, partial O, partial (m, l).
+struct Att16Layout { size_t k_off, v_off, po_off, ml_off, bytes; int npad; };
+Att16Layout attention16_layout(int B, int N, int C);
 // split_B: the batch the key split is chosen for (B, or 1 for batch-invariant plans)
-hipError_t attention16_launch(const float* qkv, float* out, void* scratch, int B, int split_B, int N, int C, int heads, hipStream_t s);
-size_t attention16_scratch_bytes(int B, int N, int C);
+hipError_t attention16_launch(const float* q, const _Float16* Kp, const _Float16* Vp, float* part_o, float* part_ml,
+                              int B, int ksplit, int tiles_per_split, int N, int C, int heads, hipStream_t s);
+// key split of the f16x3 attention for N keys: splits and 32-key tiles per split (every split owns >= 1 tile)
+void attention16_split(int N, int heads, int split_B, int* ksplit, int* tiles_per_split);
 bool attention_supported(int head_dim);
 
 // ---------------------------------------------------------------- small direct kernels

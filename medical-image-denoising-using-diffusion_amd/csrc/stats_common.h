@@ -7,8 +7,11 @@
 //             fixed order) to TOTALS with integer atomics.  A total is a 120-bit fixed-point number in three int64
 //             limbs of 40 value bits each (resolution 2^-60, range +-2^59; 24 spare bits per limb absorb up to 2^23
 //             additions without a carry): the fp32 partial converts EXACTLY, integer addition is associative, so the
-//             totals are exact and independent of the order in which workgroups finish -- bit-deterministic without a
-//             fixed-order reduction pass.  Totals are kept per BLOCK of `bs` consecutive channels, bs = the largest
+//             totals are exact (for partials of magnitude >= 2^-37; smaller ones lose their low bits, nothing a
+//             statistic of this network can see) and independent of the order in which workgroups finish --
+//             bit-deterministic without a fixed-order reduction pass.  A partial that is Inf / NaN (or >= 2^59) adds a
+//             sentinel far above any legitimate limb value instead: the total then reads as NaN, so a non-finite
+//             activation makes its whole GroupNorm group NaN, as torch's group_norm does.  Totals are kept per BLOCK of `bs` consecutive channels, bs = the largest
 //             size that every consuming GroupNorm's groups are whole multiples of (the planner knows the consumers:
 //             C/8 on the default network): a workgroup first adds its channels' limbs per block in LDS (exact), then
 //             issues one global atomic per block limb -- 6x fewer than per channel;
@@ -43,8 +46,15 @@ __device__ __forceinline__ float stat_rstd(double var_plus_eps) {
     return y;
 }
 
+// Sentinel a non-finite (or out-of-range) partial adds to the top limb, and the magnitude from which a top limb counts as
+// "not a number": legitimate top limbs stay below 2^40 * (a few hundred additions); fewer than 2^13 sentinels ever meet
+// in one total (workgroups x copies), so the sum neither wraps nor falls below the threshold.
+constexpr unsigned long long STAT_NAN_SENTINEL = 1ull << 50;
+constexpr long long STAT_NAN_THRESHOLD = 1ll << 49;
+
 __device__ __forceinline__ double stat_total(const stat_word* limbs) {
     const long long l0 = (long long)limbs[0], l1 = (long long)limbs[1], l2 = (long long)limbs[2];
+    if (l2 >= STAT_NAN_THRESHOLD || l2 <= -STAT_NAN_THRESHOLD) return __builtin_nan("");
     return (double)l0 * 0x1p-60 + (double)l1 * 0x1p-20 + (double)l2 * 0x1p20;       // each limb is exact in fp64 (|l| < 2^53)
 }
 
@@ -58,7 +68,7 @@ __device__ __forceinline__ int stat_gcd(int a, int b) { while (b) { const int t 
 __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ tot0, int C0, int bs0,
                                                 const stat_word* __restrict__ tot1, int C1, int bs1, int rep,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                double inv_n, int b, float mult, float* gnp, int tid, int nthreads) {
+                                                double inv_n, int b, float mult, float* gnp, int tid, int nthreads, int* status = nullptr) {
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const int Cin = C0 + C1, cg = Cin / GN_GROUPS_C;
     const int nb0 = C0 / bs0, nb1 = (C1 > 0) ? C1 / bs1 : 0;
@@ -86,6 +96,7 @@ __device__ __forceinline__ void gn_prologue_lds(const stat_word* __restrict__ to
         double var = stat_total(acc + STAT_LIMBS) * inv_n - mean * mean;      // biased variance, as torch's group_norm
         if (var < 0) var = 0;
         const float sc = stat_rstd(var + (double)eps) * ga;
+        if (status != nullptr && !(mean == mean && var == var)) atomicOr(status, 1);     // NaN / Inf activations (STATUS_NONFINITE): the group becomes NaN, as in torch
         gnp[c] = mult * sc;
         gnp[Cin + c] = mult * (be - (float)mean * sc);
     }
@@ -110,15 +121,15 @@ __device__ __forceinline__ void lds_barrier_raw() {
     asm volatile("" ::: "memory");
 }
 
-// Exact conversion of an fp32 partial sum to the fixed-point limbs, added into LDS block accumulators: slot[0..2].
+// Conversion of an fp32 partial sum to the fixed-point limbs (exact for 2^-37 <= |t| < 2^59), added into LDS block accumulators: slot[0..2].
 __device__ __forceinline__ void stat_add_lds(stat_word* slot, float t) {
     const unsigned u = __float_as_uint(t);
     const int ex = (int)((u >> 23) & 0xffu);
     if (ex == 0) return;                                        // zero (denormals are flushed: < 2^-126)
     unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
     int s = ex - 150 + 60;                                      // bit position of the mantissa's LSB in the fixed-point number
-    if (s < 0) { m = (s > -24) ? (m >> (-s)) : 0ull; s = 0; }
-    if (s > 95) s = 95;                                         // |t| >= 2^59 (never a finite activation statistic): pinned, no limb 3
+    if (ex == 255 || s > 95) { lds_add_raw(slot + 2, STAT_NAN_SENTINEL); return; }     // Inf / NaN, or |t| >= 2^59: the total reads as NaN
+    if (s < 0) { m = (s > -24) ? (m >> (-s)) : 0ull; s = 0; }  // |t| < 2^-37: low bits dropped
     const int k = s / 40, r = s - k * 40;
     const unsigned long long x = m << r;                        // < 2^63
     unsigned long long lo = x & ((1ull << 40) - 1ull), hi = x >> 40;
@@ -126,6 +137,45 @@ __device__ __forceinline__ void stat_add_lds(stat_word* slot, float t) {
     if (lo) lds_add_raw(slot + k, lo);
     if (hi) lds_add_raw(slot + k + 1, hi);                      // k == 2 => r <= 15 => hi == 0
 }
+
+// ---- power-of-two prescale of a RAW (not GroupNorm-ed) split-fp16 operand ------------------------------------------
+// The fp16 halves of an operand x * 2^a lose bits below fp16's subnormal floor (2^-24) and overflow above 65504, so a raw
+// operand (stride-2 / folded-ConvT / res_conv input: nothing bounds it) gets a per-(sample, conv) exponent a from the
+// sum of squares S of its source tensor(s), which the producers left in the statistics arena:  max|x| <= sqrt(S), so
+//     a = 15 - ceil(e / 2),  S = f * 2^e, f in [0.5, 1)     =>     2^a * max|x| < 2^15
+// -- no finite input can overflow, and the operand's rms sits at 2^15 / sqrt(elements) or just below (4 .. 150 for the
+// tensors of this network).  2^a is exact and is undone exactly in the epilogue (out_scale * 2^-a).
+//
+// raw_sumsq_lds: called by the 64 lanes of ONE wave; adds the sum-of-squares limbs of sample b's block totals (both
+// concatenated sources, all copies) into acc3[0..2] (LDS).  LDS instructions of one wave execute in order, so the zeroing
+// store needs no barrier before the adds; the caller's next workgroup barrier publishes acc3.
+__device__ __forceinline__ void raw_sumsq_lds(const stat_word* __restrict__ tot0, int C0, int bs0,
+                                              const stat_word* __restrict__ tot1, int C1, int bs1, int rep, int b,
+                                              stat_word* acc3, int lane) {
+    if (lane < STAT_LIMBS) lds_store_raw(acc3 + lane, 0ull);
+    const int nb0 = C0 / bs0, nb1 = (C1 > 0) ? C1 / bs1 : 0;
+    for (int e = lane; e < (nb0 + nb1) * rep; e += 64) {
+        const int blk = e / rep, r = e - blk * rep;
+        const stat_word* p = (blk < nb0) ? tot0 + (((size_t)b * nb0 + blk) * rep + r) * STAT_WORDS
+                                         : tot1 + (((size_t)b * nb1 + (blk - nb0)) * rep + r) * STAT_WORDS;
+#pragma unroll
+        for (int i = 0; i < STAT_LIMBS; ++i) {
+            const stat_word v = p[STAT_LIMBS + i];
+            if (v) lds_add_raw(acc3 + i, v);
+        }
+    }
+}
+// exponent a from the published limbs; *bad is set when the sum of squares is not finite (NaN / Inf activations)
+__device__ __forceinline__ int raw_prescale_exp(const stat_word* acc3, bool* bad) {
+    const float S = (float)stat_total(acc3);
+    *bad = !(S < __builtin_inff());                              // NaN or +Inf
+    if (!(S > 0.f) || *bad) return 0;                            // all-zero tensor: any exponent
+    const int e = (int)((__float_as_uint(S) >> 23) & 0xffu) - 126;          // S = f * 2^e, f in [0.5, 1)  (denormal S: e = -126)
+    int a = 15 - ((e + 1) >> 1);                                 // ceil(e / 2) = floor((e + 1) / 2)
+    if (a > 60) a = 60;
+    return a;                                                    // >= 15 - 64 = -49
+}
+__device__ __forceinline__ float pow2f(int a) { return __uint_as_float((unsigned)(127 + a) << 23); }      // -126 <= a <= 127
 
 // Producer side, called by ALL threads of the workgroup; TWO barriers inside (the caller's LDS rows must have been written
 // with lds_store_raw or be otherwise complete: the barriers wait for lgkmcnt(0) only).  fold(i), i in [0, 2 * ncol), returns the

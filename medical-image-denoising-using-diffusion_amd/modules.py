@@ -82,6 +82,10 @@ class UNetDiffusion(nn.Module):
         self._time_rows = DEFAULT_TIME_ROWS
         self._lock = threading.RLock()
         self._workspaces: Dict[Tuple[int, int, int, int, int], torch.Tensor] = {}
+        # After every native call the status word of its workspace is read back (mi_status: one 4-byte copy, synchronises the
+        # stream): NaN / Inf activations or an operand beyond the split-fp16 range raise MiddError instead of returning garbage.
+        # Set to False (env MIDD_CHECK_STATUS=0) to keep forward() / denoise() asynchronous; the output is NaN then, as torch's.
+        self.check_status = bool(int(os.environ.get("MIDD_CHECK_STATUS", "1")))
 
     # ------------------------------------------------------------------ native plumbing
     @property
@@ -172,6 +176,11 @@ class UNetDiffusion(nn.Module):
         if x.dtype != torch.float32:
             raise TypeError(f"{what} must be float32 (got {x.dtype})")
 
+    def _raise_on_status(self, wptr: int, stream: int) -> None:
+        if self.check_status:
+            flags = C.c_int()
+            native.check(native.lib().mi_status(wptr, stream, C.byref(flags)))
+
     # ------------------------------------------------------------------ reference interface
     @torch.no_grad()
     def forward(self, x: torch.Tensor, condition: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
@@ -195,6 +204,7 @@ class UNetDiffusion(nn.Module):
             native.check(native.lib().mi_unet_forward(
                 plan, xc.data_ptr(), cc.data_ptr(), t_host.ctypes.data_as(C.POINTER(C.c_int32)), eps.data_ptr(),
                 B, H, W, wptr, wbytes, stream))
+            self._raise_on_status(wptr, stream)
         return eps
 
     @torch.no_grad()
@@ -225,6 +235,7 @@ class UNetDiffusion(nn.Module):
                 steps.ctypes.data_as(C.POINTER(C.c_int32)), len(steps),
                 tabs[0].ctypes.data_as(fp), tabs[1].ctypes.data_as(fp), tabs[2].ctypes.data_as(fp), noise_steps,
                 nptr, native.MI_CLAMP_EPS if clamp_eps else 0, wptr, wbytes, stream))
+            self._raise_on_status(wptr, stream)
         return out
 
     @torch.no_grad()

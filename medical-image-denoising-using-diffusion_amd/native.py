@@ -17,6 +17,7 @@ MI_MAX_LEVELS = 8
 MI_VARIANT = {"ddim": 0, "cddpm": 1}
 MI_CLAMP_EPS = 1
 MI_COMPUTE = {"f32": 0, "f16x3": 1}
+MI_STATUS_NONFINITE, MI_STATUS_FP16_RANGE = 1, 2
 MI_COMPUTE_BATCH_INVARIANT = 0x100          # include/midd.h: OR into compute_mode
 
 
@@ -57,6 +58,9 @@ SYMBOLS = [
                              C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("mi_debug_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+    ("mi_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    ("mi_debug_attention_split", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("mi_source_hash", C.c_char_p, []),
     ("mi_profile_begin", C.c_int, [C.c_void_p]),
     ("mi_profile_end", C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),
     ("mi_resize_workspace_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -105,8 +109,8 @@ def check(rc: int) -> None:
         raise MiddError(rc, lib().mi_last_error().decode("utf-8", "replace"))
 
 
-def kernel_source_hash() -> str:
-    """sha256 over csrc/: identifies the kernel sources a profile (profiles/*_pmc_traffic.json) was taken from."""
+def tree_source_hash() -> str:
+    """sha256 over the csrc/ sources in the working tree (what the Makefile embeds at build time)."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -114,3 +118,9 @@ def kernel_source_hash() -> str:
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
+
+
+def kernel_source_hash() -> str:
+    """Hash of the kernel sources the LOADED library was built from (embedded at build time, mi_source_hash): identifies
+    the binary a profile (profiles/*_pmc_traffic.json) describes, whatever the working tree or MIDD_LIBRARY says."""
+    return lib().mi_source_hash().decode()

@@ -87,3 +87,22 @@ def test_container_state_dict_and_schedule():
     assert np.array_equal(d.alpha_hat.cpu().numpy(), g["alpha_hat_50"])
     with pytest.raises(RuntimeError):       # CPU tensors never silently fall back
         d.denoise(torch.zeros(1, 1, 32, 32), inference_steps=2)
+
+
+def test_attention_key_split_rule_never_leaves_an_empty_split():
+    """the doubling rule produced splits that own no tile (N = 784 = 224x224 / 64: 25 tiles, 8 splits of
+    4 tiles -> the launch returned an error).  Host-only sweep over every N and the per-program batches."""
+    lib = native.lib()
+    k, t = C.c_int(), C.c_int()
+    for B in (1, 2, 3, 4, 8, 16, 32):
+        for N in list(range(1, 1100)) + [24 * 28, 28 * 28, 36 * 36, 2048, 4095, 4096, 4097, 16384]:
+            assert lib.mi_debug_attention_split(N, B, C.byref(k), C.byref(t)) == 0
+            tiles = (N + 31) // 32
+            assert 1 <= k.value <= 8 and t.value >= 1
+            assert (k.value - 1) * t.value < tiles <= k.value * t.value, (N, B, k.value, t.value)
+    assert lib.mi_debug_attention_split(0, 1, C.byref(k), C.byref(t)) != 0
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from():
+    """profiles are matched against the BUILT binary (mi_source_hash), not the working tree."""
+    assert native.kernel_source_hash() == native.tree_source_hash(), "libmidd.so is older than csrc/: rebuild"
