@@ -44,8 +44,10 @@ struct Conv1Geom {
     }
 };
 
+// (ATT_PART_IN keeps up to four splits' partials of two K steps in registers, and its launches never fill a CU three times:
+// two workgroups per CU's worth of registers)
 template <int MT, int NT, int ATT>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, ATT == ATT_PART_IN ? 2 : 3)
 void conv1x1_f16x3_kernel(const ConvArgs a) {
     using G = Conv1Geom<MT, NT>;
     constexpr int BM = G::BM, WSTEP = G::WSTEP;
@@ -59,7 +61,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
 
     const int Cin = a.C0 + a.C1;
     const int csteps = (Cin + 31) >> 5;                       // K steps over the channels
-    const int nsteps = (ATT == ATT_PART_IN) ? csteps * a.att_ksplit : csteps;      // ... times the key splits
+    const int nsteps = csteps;
     const int HW = a.OH * a.OW;
     const int tiles = a.tiles_x;                              // ceil(HW / BM)
     const int b = blockIdx.x / a.wgs_per_img;
@@ -76,27 +78,28 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
 
     // ---- activation operand: registers, two K-steps ahead -------------------------------------
     // sequence s = 0 .. my_tiles*nsteps-1 walks (tile, step); each lane loads 8 channels of MT pixels per s
+    // (ATT_PART_IN: of up to SG key-split partials at once -- they are combined when the step is computed)
+    constexpr int SG = (ATT == ATT_PART_IN) ? 4 : 1;         // partials in flight per step (more splits: further rounds inside the step)
     const size_t img0 = (size_t)b * HW;
-    auto load_a = [&](int tile, int step, f32x4 (&r)[MT][2]) {
+    const size_t split_stride = (size_t)a.B * HW * Cin;       // ATT_PART_IN: floats between two splits' partial tensors
+    auto load_a = [&](int tile, int step, f32x4 (&r)[SG][MT][2]) {
         const float* src; int cs;
-        if constexpr (ATT == ATT_PART_IN) {
-            const int sp = step / csteps, cstep = step - sp * csteps;            // split-major: all channels of split 0, then split 1, ...
-            src = a.src0 + (size_t)sp * a.B * HW * Cin + cstep * 32 + kq * 8;
-            cs = Cin;
-        } else {
-            int ch = step * 32 + kq * 8;
-            if (ch >= Cin) ch = Cin - 8;                      // trailing half step: valid dummy, zeroed in transform
-            if (ch < a.C0) { src = a.src0 + ch; cs = a.C0; } else { src = a.src1 + (ch - a.C0); cs = a.C1; }
-        }
+        int ch = step * 32 + kq * 8;
+        if (ch >= Cin) ch = Cin - 8;                          // trailing half step: valid dummy, zeroed in transform
+        if (ch < a.C0) { src = a.src0 + ch; cs = a.C0; } else { src = a.src1 + (ch - a.C0); cs = a.C1; }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = min(tile * BM + (wave * MT + mt) * 16 + p16, HW - 1);
             const float* q = src + (img0 + p) * cs;
-            r[mt][0] = *reinterpret_cast<const f32x4*>(q);
-            r[mt][1] = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                const float* qg = q + (size_t)min(g, (ATT == ATT_PART_IN ? a.att_ksplit : 1) - 1) * split_stride;      // missing splits: a valid duplicate, coefficient 0
+                r[g][mt][0] = *reinterpret_cast<const f32x4*>(qg);
+                r[g][mt][1] = *reinterpret_cast<const f32x4*>(qg + 4);
+            }
         }
     };
-    f32x4 ra[2][MT][2];
+    f32x4 ra[2][SG][MT][2];
     const int total = my_tiles * nsteps;
     int pf_tile = first_tile, pf_step = 0;                    // next (tile, step) to request
     auto advance = [&](int& tile, int& step) { if (++step == nsteps) { step = 0; tile += a.wgs_per_img; } };
@@ -126,10 +129,43 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
             add_lds[i] = a.bias[co] + (a.temb != nullptr ? a.temb[(size_t)trow * a.temb_stride + co] : 0.f);
         }
     }
+    float rscale = a.raw_scale_fixed, oscale = a.out_scale;
+    // ATT_PART_IN: the combine coefficients of a tile, [split][head][pixel]: 2^4 * 2^(m_s - M) / (L * 2^14) -- the operand is
+    // 16 * att, like every other fixed-prescale operand.  Thread (pixel, head); splits in order; slots of missing splits (up to
+    // the next multiple of SG) hold 0.  `sync`: tiles after the first one (the first table is written in the prologue).
+    auto tile_coef = [&](int tile, bool sync) {
+        if constexpr (ATT == ATT_PART_IN) {
+            if (sync) lds_barrier();                              // every wave is done with the previous tile's table
+            const int heads = a.att_heads, ks = a.att_ksplit;
+            for (int i = tid; i < BM * heads; i += G::NTHREADS) {
+                const int head = i / BM, pix = i - head * BM;
+                const int p = min(tile * BM + pix, HW - 1);
+                const float* ml0 = a.att_ml + (((size_t)b * heads + head) * HW + p) * 2;
+                const size_t ml_stride = (size_t)a.B * heads * HW * 2;
+                float mv[C1_MAX_SPLIT], lv[C1_MAX_SPLIT];
+                float M = -INFINITY;
+#pragma unroll
+                for (int sp = 0; sp < C1_MAX_SPLIT; ++sp) {
+                    mv[sp] = -INFINITY; lv[sp] = 0.f;
+                    if (sp < ks) { mv[sp] = ml0[sp * ml_stride]; lv[sp] = ml0[sp * ml_stride + 1]; }
+                    M = fmaxf(M, mv[sp]);
+                }
+                float L = 0.f;
+#pragma unroll
+                for (int sp = 0; sp < C1_MAX_SPLIT; ++sp) { mv[sp] = __builtin_amdgcn_exp2f(mv[sp] - M); L += lv[sp] * mv[sp]; }     // missing splits: 2^-inf = 0
+                // O_s carries 2^4 (v) * 2^10 (p); l_s is the plain row sum: att = sum_s O_s w_s / (L 2^14)
+                const float inv = rscale / (L * 16384.0f);
+#pragma unroll
+                for (int sp = 0; sp < C1_MAX_SPLIT; ++sp) coef_lds[(sp * heads + head) * BM + pix] = mv[sp] * inv;
+            }
+            if (sync) lds_barrier();
+        }
+    };
+
+    if constexpr (ATT == ATT_PART_IN) tile_coef(first_tile, false);       // the first tile's table: published by the prologue's barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    float rscale = a.raw_scale_fixed, oscale = a.out_scale;
     if (a.prologue == PRO_RAW) {
         if (a.gn_tot0 != nullptr) {
             bool bad;
@@ -199,40 +235,12 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         }
     };
 
-    // ATT_PART_IN: the combine coefficients of a tile, [split][head][pixel]: 2^4 * 2^(m_s - M) / (L * 2^14) -- the operand is
-    // 16 * att, like every other fixed-prescale operand.  Thread (pixel, head); splits in order.
-    auto tile_coef = [&](int tile) {
-        if constexpr (ATT == ATT_PART_IN) {
-            lds_barrier();                                         // every wave is done with the previous tile's table
-            const int heads = a.att_heads, ks = a.att_ksplit;
-            for (int i = tid; i < BM * heads; i += G::NTHREADS) {
-                const int head = i / BM, pix = i - head * BM;
-                const int p = min(tile * BM + pix, HW - 1);
-                // three passes over the splits' (m, l) pairs (L1 / L2 hits) instead of arrays: registers are what this kernel is short of
-                const float* ml0 = a.att_ml + (((size_t)b * heads + head) * HW + p) * 2;
-                const size_t ml_stride = (size_t)a.B * heads * HW * 2;
-                float M = -INFINITY;
-#pragma unroll 1
-                for (int sp = 0; sp < ks; ++sp) M = fmaxf(M, ml0[sp * ml_stride]);
-                float L = 0.f;
-#pragma unroll 1
-                for (int sp = 0; sp < ks; ++sp) L += ml0[sp * ml_stride + 1] * __builtin_amdgcn_exp2f(ml0[sp * ml_stride] - M);
-                // O_s carries 2^4 (v) * 2^10 (p); l_s is the plain row sum: att = sum_s O_s w_s / (L 2^14)
-                const float inv = rscale / (L * 16384.0f);
-#pragma unroll 1
-                for (int sp = 0; sp < ks; ++sp) coef_lds[(sp * heads + head) * BM + pix] = __builtin_amdgcn_exp2f(ml0[sp * ml_stride] - M) * inv;
-            }
-            lds_barrier();
-        }
-    };
-
     // ---- K loop: transform (registers) -> request the load two steps ahead -> MFMAs --------------
     int c_tile = first_tile, c_step = 0;
-    auto compute = [&](f32x4 (&r)[MT][2], bool more) {
-        int cstep = c_step, sp = 0;
+    auto compute = [&](f32x4 (&r)[SG][MT][2], bool more) {
+        const int cstep = c_step;
         if constexpr (ATT == ATT_PART_IN) {
-            if (c_step == 0) tile_coef(c_tile);
-            sp = c_step / csteps; cstep = c_step - sp * csteps;
+            if (c_step == 0 && c_tile != first_tile) tile_coef(c_tile, true);
         }
         const int ch = cstep * 32 + kq * 8;
         const bool valid = ch < Cin;
@@ -247,10 +255,26 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt) {
             f32x4 v0, v1;
             if constexpr (ATT == ATT_PART_IN) {
-                const float cf = coef_lds[(sp * a.att_heads + ch / a.att_D) * BM + (wave * MT + mt) * 16 + p16];
-                v0 = r[mt][0] * cf; v1 = r[mt][1] * cf;
+                // att (x 16) = sum over the splits, in split order, of partial * coefficient[split][head][pixel]
+                const float* cf = coef_lds + (ch / a.att_D) * BM + (wave * MT + mt) * 16 + p16;
+                const int cstride = a.att_heads * BM;
+                v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0;
+#pragma unroll
+                for (int g = 0; g < SG; ++g) { const float c = cf[g * cstride]; v0 += r[g][mt][0] * c; v1 += r[g][mt][1] * c; }
+                for (int g0 = SG; g0 < a.att_ksplit; g0 += SG) {          // more than SG splits (small batches): further rounds, loaded here
+                    f32x4 t[SG][2];
+                    const int p = min(c_tile * BM + (wave * MT + mt) * 16 + p16, HW - 1);
+                    const float* q = a.src0 + ch + (img0 + p) * Cin;
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) {
+                        const float* qg = q + (size_t)min(g0 + g, a.att_ksplit - 1) * split_stride;
+                        t[g][0] = *reinterpret_cast<const f32x4*>(qg); t[g][1] = *reinterpret_cast<const f32x4*>(qg + 4);
+                    }
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) { const float c = cf[(g0 + g) * cstride]; v0 += t[g][0] * c; v1 += t[g][1] * c; }
+                }
             } else {
-                v0 = r[mt][0] * sc0 + sh0; v1 = r[mt][1] * sc1 + sh1;
+                v0 = r[0][mt][0] * sc0 + sh0; v1 = r[0][mt][1] * sc1 + sh1;
             }
             if (a.prologue == PRO_GN_SILU) {
 #pragma unroll

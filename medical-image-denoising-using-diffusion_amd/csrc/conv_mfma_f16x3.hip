@@ -103,7 +103,7 @@ __device__ __forceinline__ unsigned long long ts_stamp() {
 #define TS(k)
 #endif
 
-template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES>
 #ifndef MIDD_CONV16_WAVES_PER_SIMD
 #define MIDD_CONV16_WAVES_PER_SIMD 3
 #endif
@@ -150,7 +150,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int nchunks = (nblk + CB - 1) / CB;
     const int ntiles_total = a.Cout >> 4;
     const int ntile_wg = blockIdx.y * (WN * NT);          // first cout tile of this workgroup
-    const int total_steps = conv16_num_steps(Cin, TAPS);
+    const int res_steps = RES ? a.res_steps : 0;          // folded res_conv: K steps after a tile's 3x3 steps (instantiations of their own: registers)
+    const int total_steps = conv16_num_steps(Cin, TAPS) + res_steps;
 
     // ---- weights: LDS-DMA ring ---------------------------------------------------------------
     // global layout [step][cout tile][hi|lo][lane] x 16 B; the workgroup's slice of one step is
@@ -330,6 +331,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     stat_word* const raw_acc = reinterpret_cast<stat_word*>(gnp);
     if (a.prologue == PRO_RAW && a.gn_tot0 != nullptr && wave == 0)
         raw_sumsq_lds(a.gn_tot0, a.C0, a.gn_bs0, a.gn_tot1, a.C1, a.gn_bs1, a.stat_rep, b, raw_acc, lane);
+    // folded res_conv: its operand is the (raw) block input; same prescale rule, from the block input's totals
+    stat_word* const res_acc = reinterpret_cast<stat_word*>(gnp + 2 * Cin);          // the 64 spare bytes behind the scale / shift table
+    if (res_steps > 0 && a.res_tot0 != nullptr && wave == NW - 1)
+        raw_sumsq_lds(a.res_tot0, a.res_C0, a.res_bs0, a.res_tot1, a.res_C1, a.res_bs1, a.stat_rep, b, res_acc, lane);
     {
         const int trow = (a.temb != nullptr) ? a.trow[b] : 0;
         for (int i = tid; i < G::ADD_FLOATS; i += NTHREADS) {
@@ -348,6 +353,17 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             if (bad && tid == 0 && a.status != nullptr) atomicOr(a.status, (int)STATUS_NONFINITE);
         }
         oscale = a.out_scale / rscale;      // power of two: exact
+    }
+    float res_in = 1.0f, res_rescale = 1.0f;    // res phase: operand prescale 2^a; accumulator factor between the two products' units
+    if (res_steps > 0) {
+        if (a.res_tot0 != nullptr) {
+            bool bad;
+            res_in = pow2f(__builtin_amdgcn_readfirstlane(raw_prescale_exp(res_acc, &bad)));
+            if (bad && tid == 0 && a.status != nullptr) atomicOr(a.status, (int)STATUS_NONFINITE);
+        }
+        // 3x3 product: true value = acc * out_scale;  res product: true value = acc * res_scale / res_in  (all powers of two)
+        res_rescale = a.out_scale * res_in / a.res_scale;
+        oscale = a.res_scale / res_in;
     }
     transform(0);
     if constexpr (WM == 1) {
@@ -426,6 +442,116 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         TS(TS_MFMA)
     };
 
+    // ---- res_conv folded into the tile (ConvArgs::res_*; SURVEY 2.1, DDIMModel.py:126,133) -------------------------------
+    // After a tile's 3x3 steps the accumulators are rescaled (power of two) and res_steps more K steps run over the BLOCK
+    // INPUT's channels, 32 per step: the 1x1 res_conv.  No halo, no taps, every wave needs only ITS pixels: the B operand comes
+    // straight from global memory into registers (lane = (pixel, 8 channels), as conv1x1_f16x3.hip), two steps ahead, through
+    // loads the compiler does not track (a tracked load is awaited with vmcnt(0) while LDS-DMA is pending); the weights are
+    // further steps of the same ring.  Replaces 15 launches per forward, their output tensors and conv2's residual read.
+    // vmcnt bookkeeping per wave, program order:  A(0) A(1) | it 0: W A(2) | it 1: W A(3) | ...   (W = issue_w, PPW pieces;
+    // A = RL loads).  Iteration r needs A(r): younger are the W of iteration r-1 (r >= 1) and A(r+1) (if any).  The ring slot
+    // of step r was requested D >= 2 iterations (or 3x3 steps) earlier, i.e. before A(r): complete with it.
+    constexpr int RL = 2 * MT;                            // untracked 16-byte loads per wave and res step
+    constexpr int RG = (MT == 1) ? 2 : 1;                 // res steps per group: the loads of group g+1 fly under the MFMAs of group g
+    auto res_load = [&](int r, f32x4 (&dst)[MT][2]) {
+        const int rc = a.res_C0 + a.res_C1;
+        int ch = r * 32 + kq * 8;
+        if (ch >= rc) ch = rc - 8;                        // trailing half step: valid dummy, meets zero weights
+        const float* src; int cs;
+        if (ch < a.res_C0) { src = a.res_src0 + ch; cs = a.res_C0; } else { src = a.res_src1 + (ch - a.res_C0); cs = a.res_C1; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pp = (wm * MT + mt) * 16 + p16;
+            const int py = pp / TW, px = pp - py * TW;
+            const int oy = min(oy0 + py, a.OH - 1), ox = min(ox0 + px, a.OW - 1);
+            const float* q = src + ((size_t)(b * a.OH + oy) * a.OW + ox) * cs;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst[mt][0]) : "v"(q) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(dst[mt][1]) : "v"(q) : "memory");
+        }
+    };
+    // The raw registers of a group are written by the load statements and named again ("+v") by ONE wait statement: no
+    // use of them can be scheduled above the wait.  Loads and wait of a group sit in the SAME loop iteration, so the
+    // compiler has no loop-carried copy of them to make before the data has landed (it did, with the raw registers
+    // carried across iterations: copies of not-yet-loaded registers, NaN); what crosses iterations are the split
+    // operands, ordinary values.
+    auto res_wait = [&](f32x4 (&r)[RG][MT][2], auto n_t) {
+        constexpr int N = decltype(n_t)::value;
+        if constexpr (MT == 2) asm volatile("s_waitcnt vmcnt(%4) ; asm-loads-landed" : "+v"(r[0][0][0]), "+v"(r[0][0][1]), "+v"(r[0][1][0]), "+v"(r[0][1][1]) : "n"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%4) ; asm-loads-landed" : "+v"(r[0][0][0]), "+v"(r[0][0][1]), "+v"(r[1][0][0]), "+v"(r[1][0][1]) : "n"(N) : "memory");
+    };
+    static_assert((MT == 2 && RG == 1) || (MT == 1 && RG == 2), "res_wait names exactly the registers of one group");
+    half8 rxh[RG][MT], rxl[RG][MT];                       // split operands of the current group
+    auto res_split = [&](int r, f32x4 (&ra)[MT][2], half8 (&oh)[MT], half8 (&ol)[MT]) {
+        const bool valid = r * 32 + kq * 8 < a.res_C0 + a.res_C1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v0 = ra[mt][0] * res_in, v1 = ra[mt][1] * res_in;
+            if (!valid) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }        // keep the dummy finite
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 hw, lw;
+            unsigned hh, ll;
+            split_pair(v0[0], v0[1], hh, ll); hw[0] = hh; lw[0] = ll;
+            split_pair(v0[2], v0[3], hh, ll); hw[1] = hh; lw[1] = ll;
+            split_pair(v1[0], v1[1], hh, ll); hw[2] = hh; lw[2] = ll;
+            split_pair(v1[2], v1[3], hh, ll); hw[3] = hh; lw[3] = ll;
+            oh[mt] = __builtin_bit_cast(half8, hw);
+            ol[mt] = __builtin_bit_cast(half8, lw);
+        }
+    };
+    // one res K step: the ring protocol of k_step (wait for W(step), barrier, refill), operands from registers.
+    // in_flight: the next group's RG*RL loads were issued before this step (younger than W(step): they add to the count)
+    auto res_mfma = [&](auto in_flight, half8 (&oh)[MT], half8 (&ol)[MT]) {
+        constexpr int N = (D - 1) * PPW + (decltype(in_flight)::value ? RG * RL : 0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+        if constexpr (WM != 1) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        issue_w();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { xh[mt] = oh[mt]; xl[mt] = ol[mt]; }
+        mfma_step();
+    };
+    // vmcnt bookkeeping per wave, program order (W = issue_w: PPW pieces; A(g) = RG*RL loads of group g):
+    //   A(0) [wait 0] | group 0: A(1) W .. W [wait RG*PPW] | group 1: A(2) W .. W [wait RG*PPW] | ... | last group: W .. W
+    // A step's wait for its ring slot W(s) (requested D steps earlier, i.e. before the group's A): younger are
+    // W(s+1 .. s+D-1) and, if issued, the group's A.
+    auto res_phase = [&]() {
+        if constexpr (RES) {
+            if (res_steps == 0) return;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] *= res_rescale;
+            {
+                f32x4 ra[RG][MT][2];
+#pragma unroll
+                for (int i = 0; i < RG; ++i) res_load(min(i, res_steps - 1), ra[i]);
+                res_wait(ra, std::integral_constant<int, 0>{});
+#pragma unroll
+                for (int i = 0; i < RG; ++i) res_split(i, ra[i], rxh[i], rxl[i]);
+            }
+            for (int r = 0; r < res_steps; r += RG) {
+                const bool more = r + RG < res_steps;
+                if (more) {
+                    f32x4 ra[RG][MT][2];
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) res_load(min(r + RG + i, res_steps - 1), ra[i]);     // (a group's missing last step: a duplicate, unused)
+#pragma unroll
+                    for (int i = 0; i < RG; ++i)
+                        if (r + i < res_steps) res_mfma(std::true_type{}, rxh[i], rxl[i]);
+                    res_wait(ra, std::integral_constant<int, RG * PPW>{});
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) res_split(r + RG + i, ra[i], rxh[i], rxl[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RG; ++i)
+                        if (r + i < res_steps) res_mfma(std::false_type{}, rxh[i], rxl[i]);
+                }
+            }
+        }
+    };
+
     // ---- epilogue (per tile) ------------------------------------------------------------------
     // GroupNorm partial sums of the output run across ALL tiles of this (persistent) workgroup and are
     // published once at the end: one row per (workgroup, wave) instead of one per (tile, wave).  Per tile the
@@ -438,31 +564,44 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     auto epilogue = [&]() {
-        // The residual operand comes through loads the compiler does not track, one 16-pixel row (NT loads) at a time, awaited
-        // once: a tracked load is awaited with vmcnt(0) while LDS-DMA traffic is pending (stats_common.h), and -- vmcnt counting
-        // stores too -- that also waits for the PREVIOUS block's output store to retire: MT*NT - 1 serialised store round
-        // trips per tile instead of MT - 1.  (All MT*NT loads at once need 12 more registers than the kernel has.)
+        // The residual operand comes through loads the compiler does not track (a tracked load is awaited with vmcnt(0) while
+        // LDS-DMA traffic is pending, stats_common.h), ALL of the tile's MT*NT at once and awaited once: vmcnt counts stores
+        // too, so a wait per 16-pixel row (round 2) also waited for the previous row's output stores to retire.  The K loop's
+        // fragment registers are dead here, which is what makes room for them.
+        f32x4 rres[MT][NT];
+        size_t obase[MT];
+        bool rowok[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int pp = (wm * MT + mt) * 16 + p16;
             const int py = pp / TW, px = pp - py * TW;
             const int oy = oy0 + py, ox = ox0 + px;
-            if (oy < a.OH && ox < a.OW) {
-                const size_t o = ((size_t)(b * a.OH + oy) * a.OW + ox) * a.Cout + ntile0 * 16 + kq * 4;
-                f32x4 rres[NT];
-                if (a.resid != nullptr) {
+            rowok[mt] = oy < a.OH && ox < a.OW;
+            obase[mt] = ((size_t)(b * a.OH + min(oy, a.OH - 1)) * a.OW + min(ox, a.OW - 1)) * a.Cout + ntile0 * 16 + kq * 4;
+        }
+        if (a.resid != nullptr) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rres[nt]) : "v"(a.resid + o + nt * 16) : "memory");
-                    if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]), "+v"(rres[1]), "+v"(rres[2]) :: "memory");
-                    else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]), "+v"(rres[1]) :: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rres[0]) :: "memory");
-                }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)       // (rows beyond the image: a valid, clamped address; never stored)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rres[mt][nt]) : "v"(a.resid + obase[mt] + nt * 16) : "memory");
+            // one statement names every destination: nothing that uses (or copies) them can be scheduled above the wait
+            if constexpr (MT == 2 && NT == 3) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[0][2]), "+v"(rres[1][0]), "+v"(rres[1][1]), "+v"(rres[1][2]) :: "memory");
+            else if constexpr (MT == 2 && NT == 2) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[1][0]), "+v"(rres[1][1]) :: "memory");
+            else if constexpr (MT == 2 && NT == 1) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[1][0]) :: "memory");
+            else if constexpr (MT == 1 && NT == 3) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[0][2]) :: "memory");
+            else if constexpr (MT == 1 && NT == 2) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]) :: "memory");
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (rowok[mt]) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
                     f32x4 v = acc[mt][nt] * oscale + add;
-                    if (a.resid != nullptr) v += rres[nt];
-                    *reinterpret_cast<f32x4*>(a.out + o + nt * 16) = v;
+                    if (a.resid != nullptr) v += rres[mt][nt];
+                    *reinterpret_cast<f32x4*>(a.out + obase[mt] + nt * 16) = v;
 #if !(defined(C16_ABL) && C16_ABL == 1)  // ablation 1 (wrong results): no statistics of the output
                     ssum[nt] += v; ssq[nt] += v * v;
 #endif
@@ -552,11 +691,12 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             };
             if (more) {
                 run_chunk(std::true_type{});
-                // every wave is done reading the image, and A(next) (older than the last min(nsteps-1, D)
+                if (!more_in_tile) res_phase();         // the tile's 3x3 steps are done: the folded res_conv's steps
+                // every wave is done reading the image, and A(next) (older than the last min(steps after it, D)
                 // weight groups) has landed, before the image is rewritten
-                const int nsteps = full ? TAPS : HSTEPS;
-                if (nsteps - 1 >= D) wait_vm_and_barrier<D * PPW>();
-                else if (nsteps - 1 == 1) wait_vm_and_barrier<PPW>();
+                const int after = (full ? TAPS : HSTEPS) - 1 + (more_in_tile ? 0 : res_steps);
+                if (after >= D) wait_vm_and_barrier<D * PPW>();
+                else if (after == 1) wait_vm_and_barrier<PPW>();
                 else wait_vm_and_barrier<0>();
                 TS(TS_CHUNK_WAIT)
                 if (!more_in_tile) {                    // tile finished: store it, move to the next one
@@ -579,6 +719,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 }
             } else {
                 run_chunk(std::false_type{});
+                res_phase();
             }
         }
         if (!has_next_tile) break;
@@ -626,7 +767,7 @@ extern "C" __attribute__((visibility("default"))) void mi_debug_conv_timing_dump
     fflush(stdout);
 }
 #endif
-template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES>
 static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
     ConvArgs a = a0;
@@ -644,14 +785,14 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
         if (lds_bytes > 64 * 1024) {
             static int raised = 0;           // per instantiation
             if (lds_bytes > raised) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
                 if (e != hipSuccess) return e;
                 raised = lds_bytes;
             }
         }
         if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets
-        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN>), grid, dim3(G::NTHREADS), lds_bytes, s, a);
+        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES>), grid, dim3(G::NTHREADS), lds_bytes, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;        // tile never picked (conv16_pick_tile), not instantiated
@@ -740,9 +881,10 @@ hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
-        if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \
-        if (t.ks == 3 && t.stride == 2) return launch16<3, 2, tw_, mt_, nt_, wm_, wn_>(a, s); \
-        if (t.ks == 1 && t.stride == 1) return launch16<1, 1, tw_, mt_, nt_, wm_, wn_>(a, s); \
+        if (t.ks == 3 && t.stride == 1 && a.res_steps > 0) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_, true>(a, s); \
+        if (t.ks == 3 && t.stride == 1) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_, false>(a, s); \
+        if (t.ks == 3 && t.stride == 2) return launch16<3, 2, tw_, mt_, nt_, wm_, wn_, false>(a, s); \
+        if (t.ks == 1 && t.stride == 1) return launch16<1, 1, tw_, mt_, nt_, wm_, wn_, false>(a, s); \
     }
     MIDD_CONV16_TILES(X)
 #undef X

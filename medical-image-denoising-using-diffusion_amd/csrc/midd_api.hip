@@ -47,6 +47,7 @@ struct Mod {
     int temb_col = -1;       // column offset into the time table (residual blocks)
     // device offsets (floats) into the packed weight buffer, filled by finalize
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, wr = 0, br = 0;       // rb: conv1, conv2, res_conv
+    size_t b2r = 0;                                               // rb, f16x3, in_c != out_c: conv2's weights carry the res_conv steps (folded); bias sum
     size_t g1 = 0, be1 = 0, g2 = 0, be2 = 0;                      // rb / attn GroupNorm affine
     size_t wq = 0, bq = 0, wp = 0, bp = 0;                        // attn: qkv, proj
     size_t wc = 0, bc = 0, wt = 0;                                // down / up(folded 3x3) conv, raw ConvT
@@ -79,6 +80,8 @@ struct Op {
     ConvTile tile{};
     int stride = 1, ks = 3;
     bool want_stats = false;
+    TensorRef res0, res1;       // f16x3 conv2 with the res_conv folded in: the block input (virtual cat)
+    bool has_res1 = false; int res_steps = 0; float res_scale = 1.f;
     bool raw_stats = false;     // prologue RAW: the sources' totals exist -> per-sample power-of-two prescale (stats_common.h)
     float raw_scale_fixed = 1.f; // prologue RAW without totals: fixed prescale of the operand
     float out_scale = 1.f;
@@ -520,9 +523,23 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
                 m.g1 = put_raw(m.name + ".block1.0.weight"); m.be1 = put_raw(m.name + ".block1.0.bias");
                 m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3, &m.s1, true)); m.b1 = put_raw(m.name + ".block1.2.bias");
                 m.g2 = put_raw(m.name + ".block2.0.weight"); m.be2 = put_raw(m.name + ".block2.0.bias");
-                m.w2 = pk.put(pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3, &m.s2, true)); m.b2 = put_raw(m.name + ".block2.3.bias");
-                if (m.in_c != m.out_c) {
-                    m.wr = pk.put(pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1, &m.sr)); m.br = put_raw(m.name + ".res_conv.bias");
+                {
+                    std::vector<float> w2p = pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3, &m.s2, true);
+                    m.b2 = put_raw(m.name + ".block2.3.bias");
+                    if (m.in_c != m.out_c) {
+                        const std::vector<float> wrp = pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1, &m.sr);
+                        m.wr = pk.put(wrp); m.br = put_raw(m.name + ".res_conv.bias");
+                        if (f16) {
+                            // res_conv folded into conv2 (conv_mfma_f16x3.hip: res phase): its K steps (32 channels each, same
+                            // per-step layout) follow the 3x3 steps; one bias vector
+                            w2p.insert(w2p.end(), wrp.begin(), wrp.end());
+                            std::vector<float> bsum(m.out_c);
+                            const float* b2 = W(m.name + ".block2.3.bias"); const float* br = W(m.name + ".res_conv.bias");
+                            for (int i = 0; i < m.out_c; ++i) bsum[i] = b2[i] + br[i];
+                            m.b2r = pk.put(bsum);
+                        }
+                    }
+                    m.w2 = pk.put(w2p);
                 }
                 break;
             case MOD_ATTN:
@@ -636,6 +653,7 @@ struct Builder {
                             ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile)
                             : conv_pick_tile(dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
+        if (att_mode == ATT_PART_IN) o.tile.mt = 1;          // 64-pixel tiles: the partials of up to four splits x two K steps live in registers
         if (want_stats) { alloc_stats(dst); o.want_stats = true; }
         o.dst = dst;
         g->ops.push_back(o);
@@ -664,14 +682,19 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         if (cin != m.in_c) return fail(MI_EINVAL, "%s: expected %d input channels, graph provides %d", m.name.c_str(), m.in_c, cin);
         TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
         TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
-        // res_conv(x) first: it needs nothing but the block input.  (Running it beside conv1 on a third stream was
-        // measured: -2 % at B = 8, -4 % at B = 1 -- event traffic and a third kernel competing for the CUs.)
-        if (m.in_c != m.out_c) {
-            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, no_gn, -1, nullptr, false))) return rc;   // res_conv(x)
-        }
-        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
         const GnRef g2{m.g2, m.be2, true};
-        if (m.in_c != m.out_c) {
+        if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
+        if (m.in_c != m.out_c && p->cfg.compute_mode == MI_COMPUTE_F16X3) {
+            // res_conv(x) inside conv2's launch: extra K steps over the block input after each tile's 3x3 steps (SURVEY 2.1;
+            // round 2 ran it as a launch of its own that wrote the tensor conv2 then re-read as its residual operand)
+            if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2r, m.s2, 3, 1, PRO_GN_SILU, g2, -1, nullptr, true))) return rc;
+            Op& op = g->ops.back();
+            op.res0 = s0; if (s1) { op.res1 = *s1; op.has_res1 = true; }
+            op.res_steps = (m.in_c + 31) / 32;
+            op.res_scale = m.sr * ACT_PRESCALE_H;                  // 2^-k of the res_conv weights
+        } else if (m.in_c != m.out_c) {
+            // fp32 MFMA mode: res_conv(x) as a launch of its own, added by conv2's epilogue
+            if ((rc = bld.conv(s0, s1, o, m.wr, m.br, m.sr, 1, 1, PRO_RAW, no_gn, -1, nullptr, false))) return rc;
             const TensorRef acc = o;
             if ((rc = bld.conv(h1, nullptr, o, m.w2, m.b2, m.s2, 3, 1, PRO_GN_SILU, g2, -1, &acc, true))) return rc;   // + in place
         } else {
@@ -785,7 +808,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
     auto resolve = [&](TensorRef& t) {
         if (t.stat_id >= 0) { t.tot_off = g->stats_off + bld.stats[t.stat_id].off; t.stat_bs = bld.stats[t.stat_id].bs; }
     };
-    for (Op& o : g->ops) for (TensorRef* t : {&o.s0, &o.s1, &o.dst, &o.resid}) resolve(*t);
+    for (Op& o : g->ops) for (TensorRef* t : {&o.s0, &o.s1, &o.dst, &o.resid, &o.res0, &o.res1}) resolve(*t);
     for (auto& kv : g->outputs) resolve(kv.second);
     g->bytes = (bld.bump.cur + 255) & ~(size_t)255;
     return MI_OK;
@@ -856,14 +879,17 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
                 snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d, %d>", o.tile.mt, o.tile.nt, o.att_mode);
             else
-                snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d>",
+                snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d%s>",
                          p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
-                         o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn);
+                         o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn,
+                         p->cfg.compute_mode != MI_COMPUTE_F16X3 ? "" : (o.res_steps > 0 && o.tile.stride == 1 && o.tile.ks == 3) ? ", true" : ", false");
             *name = buf;
             const double cin = o.s0.C + (o.has_s1 ? o.s1.C : 0);
-            *flops = 2.0 * elems(o.dst) * cin * o.ks * o.ks;
+            const double res_cin = o.res_steps > 0 ? o.res0.C + (o.has_res1 ? o.res1.C : 0) : 0;      // folded res_conv (1x1 over the block input)
+            *flops = 2.0 * elems(o.dst) * (cin * o.ks * o.ks + res_cin);
             *bytes = 4.0 * (elems(o.s0) + (o.has_s1 ? elems(o.s1) : 0) + elems(o.dst) + (o.has_resid ? elems(o.resid) : 0)
-                            + (double)o.dst.C * cin * o.ks * o.ks);
+                            + (o.res_steps > 0 ? elems(o.res0) + (o.has_res1 ? elems(o.res1) : 0) : 0)
+                            + (double)o.dst.C * (cin * o.ks * o.ks + res_cin));
             break;
         }
         case OP_ATTN: {
@@ -926,6 +952,17 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* 
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue; a.stat_rep = g->stat_rep;
                 a.raw_scale_fixed = o.raw_scale_fixed; a.status = status;
+                static const bool dbg_nores = getenv("MIDD_DEBUG_NORES") != nullptr;
+                if (o.res_steps > 0 && !dbg_nores) {
+                    a.res_steps = o.res_steps; a.res_scale = o.res_scale;
+                    a.res_src0 = F(o.res0.off); a.res_C0 = o.res0.C;
+                    a.res_src1 = o.has_res1 ? F(o.res1.off) : nullptr; a.res_C1 = o.has_res1 ? o.res1.C : 0;
+                    static const bool dbg_nores_tot = getenv("MIDD_DEBUG_NORESTOT") != nullptr;
+                    if (!dbg_nores_tot && o.res0.stat_id >= 0 && (!o.has_res1 || o.res1.stat_id >= 0)) {
+                        a.res_tot0 = T(o.res0.tot_off); a.res_bs0 = o.res0.stat_bs;
+                        a.res_tot1 = o.has_res1 ? T(o.res1.tot_off) : T(o.res0.tot_off); a.res_bs1 = o.has_res1 ? o.res1.stat_bs : 1;
+                    }
+                }
                 if (o.att_mode != ATT_NONE) {
                     const Att16Layout lay = attention16_layout(B, o.dst.H * o.dst.W, o.att_mode == ATT_QKV_OUT ? o.dst.C / 3 : o.dst.C);
                     a.att_mode = o.att_mode; a.att_heads = ATTN_HEADS_ABI; a.att_D = (o.att_mode == ATT_QKV_OUT ? o.dst.C / 3 : o.dst.C) / ATTN_HEADS_ABI;

@@ -42,6 +42,16 @@ struct ConvArgs {
     stat_word* stat_tot;
     int stat_rep;           // copies of every totals block of this program (stats_common.h), also for gn_tot0/1
     int stat_bs;            // channels per totals block of the OUTPUT
+    // res_conv folded into conv2 (f16x3 3x3 kernel; res_steps == 0 everywhere else): after a tile's 3x3 steps the kernel runs
+    // res_steps more K steps of 32 channels each -- the 1x1 res_conv over the BLOCK INPUT (res_src0 [, res_src1]: the virtual
+    // torch.cat), operands straight from global memory as in conv1x1_f16x3.hip -- into the same accumulators (rescaled by the
+    // power of two between the two products' prescales).  wpack holds the 3x3 steps followed by the res steps; bias is the sum
+    // of both biases; res_tot* are the block input's totals (per-sample operand prescale, stats_common.h)
+    const float* res_src0; const float* res_src1;
+    int res_C0, res_C1, res_steps;
+    float res_scale;        // 2^-k of the res_conv weights
+    const stat_word* res_tot0; const stat_word* res_tot1;
+    int res_bs0, res_bs1;
     // attention hand-off of the f16x3 1x1 kernel (conv1x1_f16x3.hip; att_mode == ATT_NONE everywhere else)
     //   ATT_QKV_OUT  (the qkv projection): q goes to `out` as fp32 [B][N][C]; k and v are written as the split-fp16 images
     //                the attention kernel stages, att_k / att_v [B][heads][hi|lo][Npad][D] (x 2^4), keys >= N zeroed

@@ -367,5 +367,7 @@ def test_launched_kernels():
     print(sorted(names), sum(p["launches"] for p in prof), "launches")
     assert names == {"midd::in_conv_kernel", "midd::conv_mfma_f16x3_kernel", "midd::conv1x1_f16x3_kernel",
                      "midd::attention_f16x3_kernel", "midd::resize_bilinear_kernel", "midd::out_conv_kernel"}
-    # 143 in round 1: 51 GroupNorm finalize launches and 4 statistics passes (now in the producers' epilogues) are gone
-    assert sum(p["launches"] for p in prof) == 88
+    # 143 in round 1: 51 GroupNorm finalize launches and 4 statistics passes (now in the producers' epilogues) are gone;
+    # 100 in round 2 (88 ops, an attention op being prep + attention + combine); round 3: every op is ONE launch, the 15
+    # res_conv launches are K steps of their block's conv2 and an attention block is qkv -> attention -> proj: 73
+    assert sum(p["launches"] for p in prof) == 73
