@@ -615,7 +615,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // the tensor's totals with exact integer atomics (stats_common.h)
     auto publish_stats = [&]() {
         if (a.stat_tot == nullptr) return;
-#if defined(C16_ABL) && C16_ABL == 1
+#if defined(C16_ABL) && (C16_ABL == 1 || C16_ABL == 9)      // ablation 9 (wrong results): sums accumulated, never published
         return;
 #endif
         float* const my_stat = stat_lds + wave * (2 * NT * 16) + kq * 4;

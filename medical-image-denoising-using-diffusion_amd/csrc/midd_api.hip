@@ -824,7 +824,7 @@ static int get_program(mi_plan* p, int B, int H, int W, Program** out, bool side
     auto it = p->programs.find(key);
     if (it == p->programs.end()) {
         std::unique_ptr<Program> g(new Program());
-        g->persist_wgs = side_by_side ? 640 : 0;
+        g->persist_wgs = side_by_side ? 640 : 0;      // (same-box sweep in round 3: 512 .. 640 within 0.3 %, 448 and 704 .. 768 lose 1 %)
         // batch-invariant: the persistent workgroups PER SAMPLE (and with them the grouping of the statistics' partial
         // sums) must not depend on B: target / (B * ny) workgroups per sample with target = 768 B
         if (p->batch_invariant) g->persist_wgs = 768 * B;
@@ -952,13 +952,11 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* 
                 a.wpack = wd + o.w; a.bias = wd + o.b; a.Cout = o.dst.C;
                 a.prologue = o.prologue; a.stat_rep = g->stat_rep;
                 a.raw_scale_fixed = o.raw_scale_fixed; a.status = status;
-                static const bool dbg_nores = getenv("MIDD_DEBUG_NORES") != nullptr;
-                if (o.res_steps > 0 && !dbg_nores) {
+                if (o.res_steps > 0) {
                     a.res_steps = o.res_steps; a.res_scale = o.res_scale;
                     a.res_src0 = F(o.res0.off); a.res_C0 = o.res0.C;
                     a.res_src1 = o.has_res1 ? F(o.res1.off) : nullptr; a.res_C1 = o.has_res1 ? o.res1.C : 0;
-                    static const bool dbg_nores_tot = getenv("MIDD_DEBUG_NORESTOT") != nullptr;
-                    if (!dbg_nores_tot && o.res0.stat_id >= 0 && (!o.has_res1 || o.res1.stat_id >= 0)) {
+                    if (o.res0.stat_id >= 0 && (!o.has_res1 || o.res1.stat_id >= 0)) {
                         a.res_tot0 = T(o.res0.tot_off); a.res_bs0 = o.res0.stat_bs;
                         a.res_tot1 = o.has_res1 ? T(o.res1.tot_off) : T(o.res0.tot_off); a.res_bs1 = o.has_res1 ? o.res1.stat_bs : 1;
                     }
@@ -1016,7 +1014,9 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* 
             }
         }
         if (e != hipSuccess) return fail(MI_EHIP, "kernel launch (op kind %d) failed: %s", (int)o.kind, hipGetErrorString(e));
-        const size_t mid_at = g->ops.size() / mid_div;
+        // phase offset of the next sub-batch: it starts when this one has passed 1/(2 parts) of its ops -- a quarter of a forward
+        // for two sub-batches (same-box sweep of 25 / 35 / 50 / 65 / 75 %: 46.4 / 46.1 / 45.7 / 45.9 / 45.9 images/s; round 2 used 50 %)
+        const size_t mid_at = g->ops.size() / (2 * (size_t)mid_div);
         if (mid_event && (size_t)(&o - g->ops.data()) == mid_at) (void)hipEventRecord(mid_event, s);
         if (p->profiling) {
             (void)hipEventRecord(ev_b, s);
