@@ -278,6 +278,16 @@ def main():
         result["roofline"]["frac_rocprof"] = (dom["flops"] / dom["launches"] / (rp_us * 1e-6) / peak) if rp_us else None
         result["roofline"]["rocprof_avg_launch_us"] = rp_us
         result["roofline"]["rocprof_source"] = rp_src
+        # the same kernel with nothing else on the chip: one more pass as ONE program on one stream (MI_NO_SPLIT)
+        model.profile_begin()
+        model.run_sampler(noisy, timestep_list(args.noise_steps, args.inference_steps), den.beta, den.alpha, den.alpha_hat, clamp_eps=True, no_split=True)
+        alone = {p["name"]: p for p in model.profile_end()}
+        big = max((p for p in alone.values() if p["flops"] > 0), key=lambda p: p["total_ms"])
+        result["roofline"]["alone"] = {
+            "what": "the dominant kernel of the same batch run as one program on one stream (no co-resident kernel)",
+            "kernel": big["name"], "achieved": big["flops"] / (big["total_ms"] * 1e-3) / 1e12,
+            "frac": big["flops"] / (big["total_ms"] * 1e-3) / peak, "avg_launch_us": 1e3 * big["total_ms"] / big["launches"],
+            "launches": big["launches"]}
         gf = GF_PER_IMAGE_STEP.get(S)
         if gf:
             per_gpu_rate = (value / world) * n_iters          # image-steps per second per GPU

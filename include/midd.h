@@ -60,6 +60,8 @@ extern "C" {
 
 /* sampler flags for mi_denoise */
 #define MI_CLAMP_EPS     1   /* clamp(eps,-5,5) before the update: DDIMModel.py:278 (absent in cddpm) */
+#define MI_NO_SPLIT      2   /* run the batch as ONE program on the caller's stream (default: two half-batches on two streams);
+                                same results to rounding (per-program batch changes the tiles), used by bench.py's roofline leg */
 
 typedef struct mi_plan mi_plan;
 
@@ -119,7 +121,7 @@ int mi_unet_forward(mi_plan* plan, const float* x, const float* condition, const
  *   beta/alpha/alpha_hat  HOST fp32[noise_steps]
  *   step_noise device fp32 [n_iters,B,C,H,W] or NULL: the already 0.5-scaled Gaussian noise of
  *              the cddpm variant (cddpmModels.py:297-302); entry i is ignored when t_list[i]==0
- *   flags      MI_CLAMP_EPS for the DDIM variant */
+ *   flags      MI_CLAMP_EPS for the DDIM variant; MI_NO_SPLIT */
 int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B, int H, int W,
                const int32_t* t_list, int n_iters,
                const float* beta, const float* alpha, const float* alpha_hat, int noise_steps,

@@ -76,7 +76,9 @@ struct Conv16Geom {
 #define MIDD_RING_MAX 6
 #endif
     // 52 KB: three workgroups per CU
-    static constexpr int LDS_TARGET = MIDD_LDS_TARGET_KB * 1024;
+    // (stride-2 tiles stage a 33x17 halo and run one workgroup per CU whatever the ring: they take a deep ring -- with two
+    // slots the counted wait for a step's weights was 18-33 % of a wave's time, in-kernel stamps of round 3)
+    static constexpr int LDS_TARGET = (STRIDE == 2 ? 120 : MIDD_LDS_TARGET_KB) * 1024;
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;                 // at NOMINAL_CIN
@@ -87,7 +89,7 @@ struct Conv16Geom {
 // Diagnostic build only (-DMIDD_CONV_TIMING, tools/conv_timing.py): s_memtime stamps of wave 0 of every
 // workgroup, summed per launch shape.  Shares, not run times: the stamps drain the LDS queue.
 #ifdef MIDD_CONV_TIMING
-enum { TS_WAIT, TS_ISSUE, TS_MFMA, TS_CHUNK_WAIT, TS_TRANSFORM, TS_EPILOGUE, TS_PROLOGUE, TS_FIRSTWAIT, TS_DMAWAIT, TS_TOTAL, TS_REAL, TS_WGS, TS_N };
+enum { TS_WAIT, TS_ISSUE, TS_MFMA, TS_CHUNK_WAIT, TS_TRANSFORM, TS_EPILOGUE, TS_PROLOGUE, TS_FIRSTWAIT, TS_DMAWAIT, TS_RES, TS_PUBLISH, TS_TOTAL, TS_REAL, TS_WGS, TS_N };
 __device__ unsigned long long g_conv_timing[64][TS_N];
 __device__ __forceinline__ unsigned long long ts_stamp() {
     unsigned long long t;
@@ -169,7 +171,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             // WM == 1: every wave owns a distinct cout slice, so it fetches exactly the pieces it
             // reads itself (no cross-wave hand-off, no barrier per step); otherwise round-robin.
             int piece = (WM == 1) ? wave * PPW + i : wave + i * NW;
-            if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place
+            if (piece >= G::WPIECES) piece -= G::WPIECES;          // padding duplicate: same bytes, same place (issuing only the
+                                                                   // WPIECES distinct pieces, with per-wave wait counts, measured -1 %: round 3)
             dma16(wr_src + piece * 1024 + lane16, slot + piece * 1024);
         }
         ++wr_step; wr_src += wstep_bytes;
@@ -691,7 +694,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             };
             if (more) {
                 run_chunk(std::true_type{});
-                if (!more_in_tile) res_phase();         // the tile's 3x3 steps are done: the folded res_conv's steps
+                if (!more_in_tile) { res_phase(); TS(TS_RES) }         // the tile's 3x3 steps are done: the folded res_conv's steps
                 // every wave is done reading the image, and A(next) (older than the last min(steps after it, D)
                 // weight groups) has landed, before the image is rewritten
                 const int after = (full ? TAPS : HSTEPS) - 1 + (more_in_tile ? 0 : res_steps);
@@ -720,6 +723,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             } else {
                 run_chunk(std::false_type{});
                 res_phase();
+                TS(TS_RES)
             }
         }
         if (!has_next_tile) break;
@@ -727,8 +731,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the weight refills issued past the last step
     TS(TS_CHUNK_WAIT)
     epilogue();
-    publish_stats();
     TS(TS_EPILOGUE)
+    publish_stats();
+    TS(TS_PUBLISH)
 #ifdef MIDD_CONV_TIMING
     if (tid == 0) {
         ts_acc[TS_TOTAL] = ts_last - ts_t0;
@@ -754,12 +759,12 @@ extern "C" __attribute__((visibility("default"))) void mi_debug_conv_timing_dump
     static unsigned long long h[64][TS_N];
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_timing), sizeof h);
-    static const char* names[] = {"barrier", "dma-issue", "frag+mfma", "chunk-wait", "transform", "epilogue", "prologue", "wait-after-epi", "dma-wait"};
+    static const char* names[] = {"barrier", "dma-issue", "frag+mfma", "chunk-wait", "transform", "epilogue", "prologue", "wait-after-epi", "dma-wait", "res-phase", "publish"};
     for (size_t i = 0; i < g_timing_names.size(); ++i) {
         const double tot = (double)h[i][TS_TOTAL], wgs = (double)h[i][TS_WGS];
         if (wgs == 0) continue;
         printf("%-70s cyc/wg %9.0f clk %.2f GHz |", g_timing_names[i].c_str(), tot / wgs, tot / (double)h[i][TS_REAL] * 0.1);
-        for (int k = 0; k < 9; ++k) printf(" %s %4.1f%%", names[k], 100.0 * (double)h[i][k] / tot);
+        for (int k = 0; k < 11; ++k) printf(" %s %4.1f%%", names[k], 100.0 * (double)h[i][k] / tot);
         printf("\n");
     }
     memset(h, 0, sizeof h);
@@ -838,7 +843,7 @@ static bool tile16_fits(const Tile16& d, int ks, int stride) {
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
     const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4 + 64;
-    long ring = ((long)MIDD_LDS_TARGET_KB * 1024 - fixed) / (wpieces * 1024);
+    long ring = ((long)(stride == 2 ? 120 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;

