@@ -38,7 +38,7 @@
 
 namespace midd {
 
-template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN>
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, int CBT = 0>
 struct Conv16Geom {
     static constexpr int NW = WM * WN;
     static constexpr int NTHREADS = NW * 64;
@@ -47,7 +47,8 @@ struct Conv16Geom {
     static constexpr int IH = (TH - 1) * STRIDE + KS;
     static constexpr int IW = (TW - 1) * STRIDE + KS;
     static constexpr int NPIX = IH * IW;
-    static constexpr int CB = conv16_cb(KS);                        // 16-channel blocks per chunk
+    static constexpr int CB = CBT ? CBT : conv16_cb(KS);            // 16-channel blocks per chunk (CBT = 2: the "wide" 3x3 variant)
+    static constexpr bool WIDE = (KS == 3 && CB == 2);
     static constexpr int QPP = 4 * CB;                              // 16-byte slots per halo pixel and chunk
     static constexpr int NSLOT = NPIX * QPP;
     static constexpr int APW = (NSLOT + NTHREADS - 1) / NTHREADS;   // activation DMA pieces per wave and chunk
@@ -78,7 +79,11 @@ struct Conv16Geom {
     // 52 KB: three workgroups per CU
     // (stride-2 tiles stage a 33x17 halo and run one workgroup per CU whatever the ring: they take a deep ring -- with two
     // slots the counted wait for a step's weights was 18-33 % of a wave's time, in-kernel stamps of round 3)
-    static constexpr int LDS_TARGET = (STRIDE == 2 ? 120 : MIDD_LDS_TARGET_KB) * 1024;
+    // wide 3x3 chunks (launches that leave at most ~2 workgroups per CU anyway): two workgroups per CU
+#ifndef MIDD_LDS_WIDE_KB
+#define MIDD_LDS_WIDE_KB 78
+#endif
+    static constexpr int LDS_TARGET = (STRIDE == 2 ? 120 : WIDE ? MIDD_LDS_WIDE_KB : MIDD_LDS_TARGET_KB) * 1024;
     static constexpr int ring_fit = (LDS_TARGET - FIXED_BYTES) / WSLICE;
     static constexpr int RING = ring_fit < 2 ? 2 : (ring_fit > MIDD_RING_MAX ? MIDD_RING_MAX : ring_fit);
     static constexpr int LDS_BYTES = FIXED_BYTES + RING * WSLICE;                 // at NOMINAL_CIN
@@ -105,16 +110,17 @@ __device__ __forceinline__ unsigned long long ts_stamp() {
 #define TS(k)
 #endif
 
-template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES>
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES, int CBT>
 #ifndef MIDD_CONV16_WAVES_PER_SIMD
 #define MIDD_CONV16_WAVES_PER_SIMD 3
 #endif
 // the register budget is capped so that as many workgroups as the LDS target allows are resident
 // (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
 // (stride-2 tiles stage a 33x17 halo: their LDS allows one workgroup per CU anyway, so they get the whole register file)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && STRIDE == 1) ? MIDD_CONV16_WAVES_PER_SIMD : 1)
+// (wide chunks: two workgroups per CU by their LDS, so two waves per SIMD's worth of registers)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && STRIDE == 1) ? (CBT == 2 ? 2 : MIDD_CONV16_WAVES_PER_SIMD) : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
-    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
+    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN, CBT>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;
     constexpr int PAD = (KS == 3) ? 1 : 0;
     constexpr int NSLOT = G::NSLOT, APW = G::APW, PLANE = G::PLANE;
@@ -153,7 +159,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int ntiles_total = a.Cout >> 4;
     const int ntile_wg = blockIdx.y * (WN * NT);          // first cout tile of this workgroup
     const int res_steps = RES ? a.res_steps : 0;          // folded res_conv: K steps after a tile's 3x3 steps (instantiations of their own: registers)
-    const int total_steps = conv16_num_steps(Cin, TAPS) + res_steps;
+    const int total_steps = conv16_num_steps(Cin, TAPS, G::CB) + res_steps;
 
     // ---- weights: LDS-DMA ring ---------------------------------------------------------------
     // global layout [step][cout tile][hi|lo][lane] x 16 B; the workgroup's slice of one step is
@@ -772,9 +778,9 @@ extern "C" __attribute__((visibility("default"))) void mi_debug_conv_timing_dump
     fflush(stdout);
 }
 #endif
-template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES>
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES, int CBT = 0>
 static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
-    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN>;
+    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN, CBT>;
     ConvArgs a = a0;
     a.tiles_x = (a.OW + TW - 1) / TW;
     a.tiles_y = (a.OH + G::TH - 1) / G::TH;
@@ -782,7 +788,7 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     a.wgs_per_img = conv16_wgs_per_img(a.tiles_x * a.tiles_y, a.B, ny, a.persist_wgs);
     dim3 grid(a.B * a.wgs_per_img, ny);
 #ifdef MIDD_CONV_TIMING
-    a.dbg_slot = conv_timing_slot(KS, STRIDE, TW, MT, NT, WM, WN, a.OH, a.C0 + a.C1, a.Cout, a.B, G::RING, (int)grid.x * (int)grid.y);
+    a.dbg_slot = conv_timing_slot(KS, STRIDE, TW, MT * 10 + G::CB, NT, WM, WN, a.OH, a.C0 + a.C1, a.Cout, a.B, G::RING, (int)grid.x * (int)grid.y);
 #endif
     if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
         const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
@@ -790,14 +796,14 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
         if (lds_bytes > 64 * 1024) {
             static int raised = 0;           // per instantiation
             if (lds_bytes > raised) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES>),
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES, CBT>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
                 if (e != hipSuccess) return e;
                 raised = lds_bytes;
             }
         }
         if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets
-        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES>), grid, dim3(G::NTHREADS), lds_bytes, s, a);
+        hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES, CBT>), grid, dim3(G::NTHREADS), lds_bytes, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;        // tile never picked (conv16_pick_tile), not instantiated
@@ -835,27 +841,33 @@ static const Tile16 kTiles16[] = {
 };
 
 // run-time mirror of Conv16Geom::LDS_BYTES / the vmcnt-encoding limit, for the tile picker
-static bool tile16_fits(const Tile16& d, int ks, int stride) {
+static bool tile16_fits(const Tile16& d, int ks, int stride, int cb = 0) {
     const int nw = d.wm * d.wn, nthreads = nw * 64;
     const int bm = d.wm * d.mt * 16, th = bm / d.tw;
     const int ih = (th - 1) * stride + ks, iw = (d.tw - 1) * stride + ks;
-    const int cb = conv16_cb(ks);
+    if (cb == 0) cb = conv16_cb(ks);
+    const bool wide = ks == 3 && cb == 2;
     const int npix = ih * iw, apw = (npix * 4 * cb + nthreads - 1) / nthreads;
     const int wpieces = d.wn * d.nt * 2, ppw = (wpieces + nw - 1) / nw;
     const long fixed = (long)apw * nthreads * 16 + 2L * cb * npix * 32 + (nw * 2 * d.nt * 16 + d.wn * d.nt * 16) * 4 + 2 * 384 * 4 + 64;
-    long ring = ((long)(stride == 2 ? 120 : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
+    long ring = ((long)(stride == 2 ? 120 : wide ? MIDD_LDS_WIDE_KB : MIDD_LDS_TARGET_KB) * 1024 - fixed) / (wpieces * 1024);
     ring = ring < 2 ? 2 : (ring > MIDD_RING_MAX ? MIDD_RING_MAX : ring);
     const long lds = fixed + ring * wpieces * 1024;
     return lds <= 160 * 1024 && (ring - 2) * ppw + apw <= 60;
 }
 
-bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t) {
+// Launches whose grid is at most this many workgroups take the wide-chunk variant of the 4x1-wave tiles (they would
+// leave the third workgroup slot of a CU empty anyway).
+#ifndef MIDD_WIDE_MAX_WGS
+#define MIDD_WIDE_MAX_WGS 512
+#endif
+bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t, bool allow_wide) {
     if (Cout % 16) return false;
     if (!((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1))) return false;
     if (ks == 1 && conv1x1_pick_tile(Cin, Cout, B, OH, OW, t)) return true;      // dedicated 1x1 kernel (conv1x1_f16x3.hip)
     const int nt = (Cout % 48 == 0) ? 3 : (Cout % 32 == 0) ? 2 : 1;
     const Tile16* best = nullptr;
-    long best_score = -(1L << 60);
+    long best_score = -(1L << 60), best_wgs = 0;
     // 192, not 256 workgroups: at B=4 (half-batches) the 32x32 layers with 144 couts would otherwise drop to 32-pixel
     // 2-wave tiles that stream the weights twice as often (same-box A/B: +1.7 %)
     constexpr long min_wgs = 192;
@@ -875,15 +887,24 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
         // (forcing the 2x2-wave 96-cout tile on the <= 32x32 / <= 64x64 maps -- the GroupNorm / SiLU / split transform shared by
         // two cout slices -- measured -6.5 % / -7 %: its 12 KB weight slices leave a two-slot ring, one step in flight)
         const long score = (wgs >= min_wgs ? 1000000 : wgs * (1000000 / min_wgs)) + share - (wasteful ? 500000 : 0);
-        if (score > best_score) { best_score = score; best = &d; }
+        if (score > best_score) { best_score = score; best = &d; best_wgs = wgs; }
     }
     if (!best) return false;
     *t = ConvTile{ks, stride, best->tw, best->mt, best->nt, best->wm, best->wn};
+    if (allow_wide && ks == 3 && stride == 1 && best->tw == 16 && best->nt == 3 && best->wm == 4 && best->wn == 1 && Cin >= 32 &&
+        best_wgs <= MIDD_WIDE_MAX_WGS && tile16_fits(*best, ks, stride, 2))
+        t->cb = 2;
     return true;
 }
 
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
+    if (t.cb == 2) {          // wide chunks: the two 4x1-wave tiles the picker marks (conv16_pick_tile)
+        if (!(t.ks == 3 && t.stride == 1 && t.tw == 16 && t.nt == 3 && t.wm == 4 && t.wn == 1)) return hipErrorInvalidValue;
+        if (t.mt == 2) return a.res_steps > 0 ? launch16<3, 1, 16, 2, 3, 4, 1, true, 2>(a, s) : launch16<3, 1, 16, 2, 3, 4, 1, false, 2>(a, s);
+        if (t.mt == 1) return a.res_steps > 0 ? launch16<3, 1, 16, 1, 3, 4, 1, true, 2>(a, s) : launch16<3, 1, 16, 1, 3, 4, 1, false, 2>(a, s);
+        return hipErrorInvalidValue;
+    }
 #define X(tw_, mt_, nt_, wm_, wn_)                                                            \
     if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
         if (t.ks == 3 && t.stride == 1 && a.res_steps > 0) return launch16<3, 1, tw_, mt_, nt_, wm_, wn_, true>(a, s); \

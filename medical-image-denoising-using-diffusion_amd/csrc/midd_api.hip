@@ -47,6 +47,7 @@ struct Mod {
     int temb_col = -1;       // column offset into the time table (residual blocks)
     // device offsets (floats) into the packed weight buffer, filled by finalize
     size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0, wr = 0, br = 0;       // rb: conv1, conv2, res_conv
+    size_t w1x = (size_t)-1, w2x = (size_t)-1, wcx = (size_t)-1;  // f16x3: the same 3x3 weights in the wide-chunk K order (conv16_pick_tile: cb = 2); -1: none
     size_t b2r = 0;                                               // rb, f16x3, in_c != out_c: conv2's weights carry the res_conv steps (folded); bias sum
     size_t g1 = 0, be1 = 0, g2 = 0, be2 = 0;                      // rb / attn GroupNorm affine
     size_t wq = 0, bq = 0, wp = 0, bp = 0;                        // attn: qkv, proj
@@ -87,9 +88,17 @@ struct Op {
     float out_scale = 1.f;
 };
 
+// Batch-invariant plans (MI_COMPUTE_BATCH_INVARIANT) make every per-sample decision -- tile, persistent workgroups per
+// sample, attention key split, chunk width -- as the DEFAULT plan of a side-by-side sub-batch of this many samples does:
+// 4 = one half of BASELINE configs[1]'s batch of 8, so at that batch the invariant plan IS the default plan (no cost), larger
+// batches keep the per-image cost of batch 8 (they give up the few per cent a larger batch gains) and a single image runs
+// on the 160-workgroup grids of one quarter of a sub-batch.  (Round 2 planned as for a batch of one: -19 % at batch 8.)
+constexpr int INVARIANT_B = 4;
+
 struct Program {
     int B, H, W;
     int persist_wgs = 0;       // f16x3 convs: persistent-workgroup target of this program (0 = default)
+    bool wide_chunks = false;  // f16x3 3x3 convs may take the wide-chunk variant (conv16_pick_tile): programs that run alone
     std::vector<Op> ops;
     size_t bytes = 0, trow_off = 0;
     size_t stats_off = 0, stats_bytes = 0;      // statistics arena: every tensor's totals, zeroed by one memset per forward
@@ -99,7 +108,7 @@ struct Program {
 
 struct mi_plan {
     mi_unet_cfg cfg{};                                       // compute_mode holds the arithmetic only (flag bits stripped)
-    bool batch_invariant = false;                            // MI_COMPUTE_BATCH_INVARIANT: plan every launch as for a batch of one
+    bool batch_invariant = false;                            // MI_COMPUTE_BATCH_INVARIANT: plan every launch as for a batch of INVARIANT_B
     std::vector<Mod> downs, mid, ups;
     int final_c = 0, temb_cols = 0, levels = 0;
     std::vector<std::string> expected;                       // state-dict key order
@@ -377,7 +386,8 @@ static std::vector<float> pack_conv_f32(const float* w, int Cout, int Cin, int K
 // *out_scale = 2^-k / ACT_PRESCALE.  Returned as raw 32-bit words (two fp16 each).
 static const float ACT_PRESCALE_H = 16.0f;      // 2^s: must match ACT_PRESCALE in conv_mfma_f16x3.hip
 static const float SILU_WEIGHT_FACTOR_H = -0.6931471805599453f;     // == SILU_WEIGHT_FACTOR (f16x3_common.h): see conv_mfma_f16x3.hip, transform
-static std::vector<float> pack_conv_f16x3(const float* w_in, int Cout, int Cin, int KS, float* out_scale, float wmul = 1.0f) {
+static std::vector<float> pack_conv_f16x3(const float* w_in, int Cout, int Cin, int KS, float* out_scale, float wmul = 1.0f, int cb = 0) {
+    if (cb == 0) cb = conv16_cb(KS);                     // blocks per K chunk: the K order of the steps (midd_internal.h)
     // wmul: constant folded into the weights (fp32 product, rounded once): -ln 2 for the convolutions behind GroupNorm + SiLU,
     // whose operand the kernel forms as -16 log2(e) silu(y)
     std::vector<float> wm;
@@ -388,7 +398,7 @@ static std::vector<float> pack_conv_f16x3(const float* w_in, int Cout, int Cin, 
         w = wm.data();
     }
     const int taps = KS * KS, nblk = Cin / 16, ntile = Cout / 16;
-    const int steps = conv16_num_steps(Cin, taps);
+    const int steps = conv16_num_steps(Cin, taps, cb);
     float wmax = 0.f;
     for (size_t i = 0; i < (size_t)Cout * Cin * taps; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
     int e = 0;
@@ -419,7 +429,7 @@ static std::vector<float> pack_conv_f16x3(const float* w_in, int Cout, int Cin, 
             }
         ++step;
     };
-    if (conv16_cb(KS) == 1) {
+    if (cb == 1) {
         for (int blk = 0; blk < nblk; ++blk)
             for (int hs = 0; hs < (taps + 1) / 2; ++hs) emit(blk, blk, 2 * hs, 2 * hs + 1);
     } else {
@@ -515,6 +525,14 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
         *scale = 1.0f;
         return f16 ? pack_conv_f16x3(w, Cout, Cin, KS, scale, behind_silu ? SILU_WEIGHT_FACTOR_H : 1.0f) : pack_conv_f32(w, Cout, Cin, KS);
     };
+    // second copy of a 3x3's weights in the wide-chunk K order (same values, same scale); the planner picks per launch
+    auto pack_wide = [&](const float* w, int Cout, int Cin, bool behind_silu, const std::vector<float>* tail = nullptr) -> size_t {
+        if (!f16 || Cin < 32) return (size_t)-1;
+        float scale;
+        std::vector<float> v = pack_conv_f16x3(w, Cout, Cin, 3, &scale, behind_silu ? SILU_WEIGHT_FACTOR_H : 1.0f, 2);
+        if (tail) v.insert(v.end(), tail->begin(), tail->end());
+        return pk.put(v);
+    };
     auto W = [&](const std::string& k) { return getw(plan, k)->data.data(); };
     auto put_raw = [&](const std::string& k) { return pk.put(getw(plan, k)->data); };
     auto pack_mod = [&](Mod& m) {
@@ -522,14 +540,17 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
             case MOD_RB:
                 m.g1 = put_raw(m.name + ".block1.0.weight"); m.be1 = put_raw(m.name + ".block1.0.bias");
                 m.w1 = pk.put(pack_conv(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, 3, &m.s1, true)); m.b1 = put_raw(m.name + ".block1.2.bias");
+                m.w1x = pack_wide(W(m.name + ".block1.2.weight"), m.out_c, m.in_c, true);
                 m.g2 = put_raw(m.name + ".block2.0.weight"); m.be2 = put_raw(m.name + ".block2.0.bias");
                 {
                     std::vector<float> w2p = pack_conv(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, 3, &m.s2, true);
                     m.b2 = put_raw(m.name + ".block2.3.bias");
+                    if (m.in_c == m.out_c) m.w2x = pack_wide(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, true);
                     if (m.in_c != m.out_c) {
                         const std::vector<float> wrp = pack_conv(W(m.name + ".res_conv.weight"), m.out_c, m.in_c, 1, &m.sr);
                         m.wr = pk.put(wrp); m.br = put_raw(m.name + ".res_conv.bias");
                         if (f16) {
+                            m.w2x = pack_wide(W(m.name + ".block2.3.weight"), m.out_c, m.out_c, true, &wrp);
                             // res_conv folded into conv2 (conv_mfma_f16x3.hip: res phase): its K steps (32 channels each, same
                             // per-step layout) follow the 3x3 steps; one bias vector
                             w2p.insert(w2p.end(), wrp.begin(), wrp.end());
@@ -554,6 +575,7 @@ extern "C" int mi_unet_finalize(mi_plan* plan, int time_rows) {
                 const float* w = W(m.name + ".weight");
                 std::vector<float> eff = fold_convt(w, m.in_c, m.out_c);
                 m.wc = pk.put(pack_conv(eff.data(), m.out_c, m.in_c, 3, &m.sc)); m.bc = put_raw(m.name + ".bias");
+                m.wcx = pack_wide(eff.data(), m.out_c, m.in_c, false);
                 // raw layout [ky][kx][Cin][Cout] for the direct fallback kernel
                 std::vector<float> raw((size_t)16 * m.in_c * m.out_c);
                 for (int ci = 0; ci < m.in_c; ++ci) for (int co = 0; co < m.out_c; ++co)
@@ -611,6 +633,7 @@ struct Bump {
 
 struct Builder {
     mi_plan* p; Program* g; Bump bump; int B;
+    size_t next_wide = (size_t)-1;      // set before conv(): the wide-chunk copy of that conv's weights (consumed by the call)
     TensorRef alloc(int C, int H, int W) {
         TensorRef t; t.C = C; t.H = H; t.W = W;
         t.off = bump.take((size_t)B * H * W * C * sizeof(float));
@@ -648,11 +671,13 @@ struct Builder {
         o.w = w; o.b = b; o.ks = ks; o.stride = stride; o.prologue = prologue; o.temb_col = temb_col; o.gn = gn;
         if (gn.on) { if (int rcg = gn_consumer(s0, s1)) return rcg; }
         if (resid) { o.resid = *resid; o.has_resid = true; }
-        const int Bp = p->batch_invariant ? 1 : B;           // batch-invariant plans tile as for a batch of one
+        const int Bp = p->batch_invariant ? INVARIANT_B : B; // batch-invariant plans tile as for the canonical batch
+        const size_t w_wide = next_wide; next_wide = (size_t)-1;
         const bool ok = (p->cfg.compute_mode == MI_COMPUTE_F16X3)
-                            ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile)
+                            ? conv16_pick_tile(s0.C + (s1 ? s1->C : 0), dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile, g->wide_chunks && w_wide != (size_t)-1)
                             : conv_pick_tile(dst.C, Bp, dst.H, dst.W, ks, stride, &o.tile);
         if (!ok) return fail(MI_EINVAL, "no conv tile for Cout=%d ks=%d stride=%d", dst.C, ks, stride);
+        if (o.tile.cb == 2) o.w = w_wide;                    // the launch walks K in the wide order
         if (att_mode == ATT_PART_IN) o.tile.mt = 1;          // 64-pixel tiles: the partials of up to four splits x two K steps live in registers
         if (want_stats) { alloc_stats(dst); o.want_stats = true; }
         o.dst = dst;
@@ -683,7 +708,9 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         TensorRef h1 = bld.alloc(m.out_c, s0.H, s0.W);
         TensorRef o = bld.alloc(m.out_c, s0.H, s0.W);
         const GnRef g2{m.g2, m.be2, true};
+        bld.next_wide = m.w1x;
         if ((rc = bld.conv(s0, s1, h1, m.w1, m.b1, m.s1, 3, 1, PRO_GN_SILU, GnRef{m.g1, m.be1, true}, m.temb_col, nullptr, true))) return rc;
+        bld.next_wide = m.w2x;
         if (m.in_c != m.out_c && p->cfg.compute_mode == MI_COMPUTE_F16X3) {
             // res_conv(x) inside conv2's launch: extra K steps over the block input after each tile's 3x3 steps (SURVEY 2.1;
             // round 2 ran it as a launch of its own that wrote the tensor conv2 then re-read as its residual operand)
@@ -724,7 +751,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
         const Att16Layout lay = attention16_layout(B, N, C);
         const size_t scratch = bld.bump.take(lay.bytes);
         int ksplit = 1, tps = 1;
-        attention16_split(N, ATTN_HEADS_ABI, p->batch_invariant ? 1 : B, &ksplit, &tps);
+        attention16_split(N, ATTN_HEADS_ABI, p->batch_invariant ? INVARIANT_B : B, &ksplit, &tps);
         TensorRef qkv = bld.alloc(3 * C, x.H, x.W);            // Cout of the projection; only [B][N][C] floats (q) are written
         if ((rc = bld.conv(x, nullptr, qkv, m.wq, m.bq, m.sq, 1, 1, PRO_GN, gnorm, -1, nullptr, false, 1.0f, ATT_QKV_OUT, scratch, ksplit))) return rc;
         Op o{}; o.kind = OP_ATTN; o.s0 = qkv; o.dst = y; o.partial_off = scratch; o.att_ksplit = ksplit; o.att_tps = tps;
@@ -780,6 +807,7 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
             if (skip.H == h.H && skip.W == h.W) {
                 // ConvTranspose(4,2,1) then bilinear back to the skip's (half) size: one folded 3x3
                 TensorRef o = bld.alloc(pending_up->out_c, h.H, h.W);
+                bld.next_wide = pending_up->wcx;
                 if ((rc = bld.conv(h, nullptr, o, pending_up->wc, pending_up->bc, pending_up->sc, 3, 1, PRO_RAW, no_gn, -1, nullptr, true))) return rc;
                 h = o; pending_up = nullptr;
             } else if ((rc = flush_up())) return rc;
@@ -826,8 +854,13 @@ static int get_program(mi_plan* p, int B, int H, int W, Program** out, bool side
         std::unique_ptr<Program> g(new Program());
         g->persist_wgs = side_by_side ? 640 : 0;      // (same-box sweep in round 3: 512 .. 640 within 0.3 %, 448 and 704 .. 768 lose 1 %)
         // batch-invariant: the persistent workgroups PER SAMPLE (and with them the grouping of the statistics' partial
-        // sums) must not depend on B: target / (B * ny) workgroups per sample with target = 768 B
-        if (p->batch_invariant) g->persist_wgs = 768 * B;
+        // sums) must not depend on B or on the split: target / (B * ny) workgroups per sample with target = (640 / INVARIANT_B) B
+        if (p->batch_invariant) g->persist_wgs = 640 / INVARIANT_B * B;
+        // Wide 3x3 chunks (32 channels per chunk, 9 full K steps instead of 2 x 5, half the chunk hand-overs; 72-77 KB of LDS
+        // per workgroup) on the launches of <= 512 workgroups: same-box A/B in round 3, B = 8 at 256x256: +2.3 % for a
+        // program that runs alone, -3.5 % side by side (the other sub-batch's workgroups no longer fit beside them on a
+        // CU) -- so only programs that run alone take them.  Not in batch-invariant plans: the K order is part of the bits.
+        g->wide_chunks = !side_by_side && !p->batch_invariant;
         int rc = build_program(p, B, H, W, g.get());
         if (rc) return rc;
         it = p->programs.emplace(key, std::move(g)).first;
@@ -878,11 +911,14 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
         case OP_CONV: {
             if (p->cfg.compute_mode == MI_COMPUTE_F16X3 && o.tile.ks == 1 && o.tile.tw == 0)
                 snprintf(buf, sizeof(buf), "midd::conv1x1_f16x3_kernel<%d, %d, %d>", o.tile.mt, o.tile.nt, o.att_mode);
-            else
+            else {
+                char tail[32] = "";         // f16x3: the RES flag and the chunk width (template arguments 8 and 9)
+                if (p->cfg.compute_mode == MI_COMPUTE_F16X3)
+                    snprintf(tail, sizeof(tail), ", %s, %d", (o.res_steps > 0 && o.tile.stride == 1 && o.tile.ks == 3) ? "true" : "false", o.tile.cb);
                 snprintf(buf, sizeof(buf), "midd::conv_mfma_%s_kernel<%d, %d, %d, %d, %d, %d, %d%s>",
                          p->cfg.compute_mode == MI_COMPUTE_F16X3 ? "f16x3" : "f32", o.tile.ks, o.tile.stride,
-                         o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn,
-                         p->cfg.compute_mode != MI_COMPUTE_F16X3 ? "" : (o.res_steps > 0 && o.tile.stride == 1 && o.tile.ks == 3) ? ", true" : ", false");
+                         o.tile.tw, o.tile.mt, o.tile.nt, o.tile.wm, o.tile.wn, tail);
+            }
             *name = buf;
             const double cin = o.s0.C + (o.has_s1 ? o.s1.C : 0);
             const double res_cin = o.res_steps > 0 ? o.res0.C + (o.has_res1 ? o.res1.C : 0) : 0;      // folded res_conv (1x1 over the block input)

@@ -72,6 +72,7 @@ struct ConvArgs {
 
 struct ConvTile {           // which template instance to launch
     int ks, stride, tw, mt, nt, wm, wn;
+    int cb = 0;             // f16x3 3x3: 16-channel blocks per K chunk (0: conv16_cb(ks)); selects the weight packing too
 };
 
 enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
@@ -83,7 +84,7 @@ bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTil
 hipError_t conv_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 
 // split-fp16 variant (conv_mfma_f16x3.hip): same arguments, weights packed by pack_conv_f16x3
-bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
+bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t, bool allow_wide = false);
 int conv16_wgs_per_img(int tiles, int B, int ny, int target = 0);   // target 0: 768
 bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t);   // ConvTile::tw == 0 marks it
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);      // persistent workgroups per sample (f16x3 kernels)
@@ -93,11 +94,15 @@ hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
 //             activation LDS of a 32-channel chunk, i.e. three resident workgroups per CU)
 //   1x1: 2 -> 32 channels per chunk and step (no halo, so the image is small; halves the number of
 //             chunk hand-overs, which dominate a 1x1)
+//   3x3, "wide" (cb = 2, picked per launch where the grid leaves at most ~2 workgroups per CU anyway: the 32x32 / 64x64 maps
+//             at small batches): 32 channels per chunk, one tap per step -- 9 full steps instead of 2 x 5 (no zero-weight
+//             half step) and half the chunk hand-overs; weights packed in that K order as a second copy (pack_conv_f16x3)
 __host__ __device__ constexpr int conv16_cb(int ks) { return ks == 1 ? 2 : 1; }
-// number of 32-wide K steps the f16x3 kernel walks for (Cin, taps)
-__host__ __device__ inline int conv16_num_steps(int Cin, int taps) {
+// number of 32-wide K steps the f16x3 kernel walks for (Cin, taps) with cb blocks per chunk (0: the default of the kernel size)
+__host__ __device__ inline int conv16_num_steps(int Cin, int taps, int cb = 0) {
     const int nblk = Cin / 16;
-    if (conv16_cb(taps == 1 ? 1 : 3) == 1) return nblk * ((taps + 1) / 2);
+    if (cb == 0) cb = conv16_cb(taps == 1 ? 1 : 3);
+    if (cb == 1) return nblk * ((taps + 1) / 2);
     const int full = nblk / 2, half = nblk & 1;
     return full * taps + half * ((taps + 1) / 2);
 }

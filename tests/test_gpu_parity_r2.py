@@ -331,8 +331,8 @@ def test_statistics_are_never_stale_across_launches():
 def test_batch_invariant_mode_is_bit_exact_across_batch_sizes(compute):
     """SURVEY.md section 8e "Check": a shard must reproduce the full batch bit for bit.  By default the tiles, the persistent
     workgroups per sample and the attention key split follow the batch size, so the same image at another batch size
-    agrees to ~1e-6 only; UNetDiffusion(batch_invariant=True) plans every launch as for a batch of
-    one.  Checked for the sampler and for a single forward, at two image sizes, against batches of 1, 3, 4 and 8 -- and the
+    agrees to ~1e-6 only; UNetDiffusion(batch_invariant=True) plans every launch as the default plan
+    of a 4-sample sub-batch does, whatever the batch (round 2: as for a batch of one, -19 %).  Checked for the sampler and for a single forward, at two image sizes, against batches of 1, 3, 4 and 8 -- and the
     mode still matches the reference fixture."""
     cfg = UNetConfig()
     sd = make_state_dict(cfg, seed=42)
