@@ -903,7 +903,7 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
     auto elems = [&](const TensorRef& t) { return B * t.H * t.W * t.C; };
     switch (o.kind) {
         case OP_IN_CONV:
-            *name = "midd::in_conv_kernel";
+            *name = p->cfg.in_channels == 1 ? "midd::in_conv1_kernel" : "midd::in_conv_kernel";
             *flops = 2.0 * B * g->H * g->W * o.dst.C * 9 * 2 * p->cfg.in_channels;
             *bytes = 4.0 * (2.0 * B * p->cfg.in_channels * g->H * g->W + elems(o.dst));
             break;
@@ -942,7 +942,7 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
             *flops = 2.0 * elems(o.s0) * o.dst.C * 16; *bytes = 4.0 * (elems(o.s0) + elems(o.dst));
             break;
         case OP_OUT:
-            *name = "midd::out_conv_kernel";
+            *name = p->cfg.in_channels == 1 ? "midd::out_conv_kernel<1>" : "midd::out_conv_kernel<0>";
             *flops = 2.0 * B * g->H * g->W * o.s0.C * 9 * p->cfg.in_channels;
             *bytes = 4.0 * (elems(o.s0) + 3.0 * B * p->cfg.in_channels * g->H * g->W);
             break;

@@ -29,7 +29,7 @@ __device__ __forceinline__ float silu_pw(float v) {
 template <int NV>
 __device__ __forceinline__ void pointwise_publish(const float (&sum)[NV], const float (&sq)[NV], bool active, int pl, int ppi, int cgrp,
                                                   int C, float* scratch, stat_word* acc, stat_word* tot, int b, int bs, int rep,
-                                                  int replica, int tid) {
+                                                  int replica, int tid, int nthreads = 256) {
     if (active) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
@@ -42,7 +42,7 @@ __device__ __forceinline__ void pointwise_publish(const float (&sum)[NV], const 
         for (int l = 0; l < ppi; ++l) t += (double)scratch[(size_t)i * ppi + l];
         return (float)t;
     };
-    stat_publish(tot, b, C, bs, rep, replica, 0, C, fold, acc, tid, 256);
+    stat_publish(tot, b, C, bs, rep, replica, 0, C, fold, acc, tid, nthreads);
 }
 
 // pixels a workgroup of 256 threads walks: ~4 per pixel lane, at most 1024 workgroups per sample
@@ -91,18 +91,31 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
                     for (int dx = 0; dx < 3; ++dx) {
                         const int gx = ox + dx - 1;
                         if (gx < 0 || gx >= W) continue;
+#if defined(PW_ABL) && PW_ABL == 3      // ablation (tools/mb/pw_abl.hip, wrong results): no input loads
+                        const float v = 1.0f + (float)gx;
+#else
                         const float v = plane[(size_t)gy * W + gx];
+#endif
                         const float* wr = &wl[((dy * 3 + dx) * 2 * ic + ci) * Cout + cg * 16];
+#if defined(PW_ABL) && PW_ABL == 4      // ablation: no weight reads / multiply-adds
+                        acc[dx] += v;
+#else
 #pragma unroll
                         for (int k = 0; k < 4; ++k) acc[k] += v * *reinterpret_cast<const f32x4*>(wr + k * 4);
+#endif
                     }
                 }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+#if defined(PW_ABL) && PW_ABL == 1      // ablation: no output stores
+                if (acc[k][0] == 12345.678f)
+#endif
                 *reinterpret_cast<f32x4*>(out + ((size_t)b * HW + p) * Cout + cg * 16 + k * 4) = acc[k];
+#if !(defined(PW_ABL) && PW_ABL == 2)   // ablation: no statistics
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ssum[k * 4 + e] += acc[k][e]; ssq[k * 4 + e] += acc[k][e] * acc[k][e]; }
+#endif
             }
         }
     }
@@ -112,9 +125,160 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
     pointwise_publish<16>(ssum, ssq, active, pl, ppi, cg, Cout, scratch, acc_lds, tot, b, bs, rep, row % rep, tid);
 }
 
+
+// ------------------------------------------------------------------------------ in_conv, one input channel (the reference's grayscale case)
+// Round 3.  Ablations (tools/mb/pw_abl.hip) of the kernel above at B = 4: 36 us, 23 of them with the stores removed -- it
+// is bound by its instruction stream and its latencies (72 per-lane LDS weight reads and a branch per tap for 288
+// multiply-adds; three threads load each pixel's taps; 1.5 waves per SIMD), and its stores, 16 bytes per lane 64 bytes
+// apart, reach 2.4 TB/s where contiguous ones reach 4 (tools/mb/hbm_rate.hip).  Here every WAVE works on its own:
+//   lane = pixel, all Cout outputs of it: the weights are uniform (scalar loads, SGPR operands: no LDS, no weight
+//   registers), the 18 taps are loaded once per pixel, branch-free from clamped addresses, coalesced, one pass ahead;
+//   the wave's [64 pixels][Cout] tile is turned through its OWN LDS patch (no workgroup barrier in the loop) and
+//   leaves as whole contiguous rows, every lane 16 bytes next to its neighbour's;
+//   the statistics are summed on the values in store order: a lane meets NQ / gcd(64, NQ) different channel quads.
+// Same accumulation order per output as above: bias, then (channel, dy, dx).  grid (rows, B), 4 waves.
+template <int COUT>
+__global__ __launch_bounds__(256, 3)
+void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ w,
+                     const float* __restrict__ bias, float* __restrict__ out, stat_word* __restrict__ tot, int rep, int bs,
+                     int H, int W, int per) {
+    constexpr int NQ = COUT / 4;                                  // 16-byte pieces per pixel
+    constexpr int G64 = (NQ % 16 == 0) ? 16 : (NQ % 8 == 0) ? 8 : (NQ % 4 == 0) ? 4 : (NQ % 2 == 0) ? 2 : 1;   // gcd(64, NQ)
+    constexpr int SETS = NQ / G64;                                // channel quads a lane meets in store order
+    constexpr int PS = COUT + 4;                                  // padded pixel stride (words): 16-byte stores of 8 lanes on distinct banks
+    constexpr int SLOTS = 4 * SETS * ((64 + NQ - 1) / NQ);        // contributors per channel: (wave, set, lane / NQ)
+    extern __shared__ __attribute__((aligned(16))) float ic1_lds[];   // [4 waves][64][PS] tiles; afterwards the statistics scratch [2][COUT][SLOTS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* const tile = ic1_lds + wave * (64 * PS);
+    const int b = blockIdx.y, HW = H * W;
+    const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
+    const float* const xp = x + (size_t)b * HW;
+    const float* const cp = cond + (size_t)b * HW;
+    float ssum[SETS][4], ssq[SETS][4];
+#pragma unroll
+    for (int j = 0; j < SETS; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[j][e] = 0.f; ssq[j][e] = 0.f; }
+    auto load_taps = [&](int base, float (&v)[18]) {
+        const int pc = min(base + lane, HW - 1);
+        const int oy = pc / W, ox = pc - oy * W;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int gy = oy + dy - 1, cy = min(max(gy, 0), H - 1);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int gx = ox + dx - 1, cx = min(max(gx, 0), W - 1);
+                const bool in = (gy == cy) && (gx == cx);
+#if defined(PW_ABL) && PW_ABL == 6      // ablation (tools/mb/pw_abl.hip, wrong results): no input loads
+                const float a0 = (float)cx, a1 = (float)cy;
+#else
+                const float a0 = xp[cy * W + cx], a1 = cp[cy * W + cx];
+#endif
+                v[dy * 3 + dx] = in ? a0 : 0.f;
+                v[9 + dy * 3 + dx] = in ? a1 : 0.f;
+            }
+        }
+    };
+    float vn[18];
+    int base = p0 + wave * 64;
+    if (base < p1) load_taps(base, vn);
+    for (; base < p1; base += 256) {
+        float v[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) v[i] = vn[i];
+        if (base + 256 < p1) load_taps(base + 256, vn);           // next pass's taps fly under this pass's arithmetic
+        int wofs = 0;                                             // opaque per pass: otherwise all 18 * COUT weights are hoisted out of the
+        asm volatile("" : "+s"(wofs));                            // loop as loop invariants -- 864 SGPRs, spilled to VGPR lanes
+        const float* const wp = w + wofs;
+        f32x4 acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = *reinterpret_cast<const f32x4*>(bias + q * 4);
+#if defined(PW_ABL) && PW_ABL == 7      // ablation: two taps instead of 18
+        for (int i = 0; i < 2; ++i) {
+#else
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {                            // i = ci * 9 + tap
+#endif
+            const float* wr = wp + ((i % 9) * 2 + i / 9) * COUT;  // uniform: scalar loads
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] += v[i] * *reinterpret_cast<const f32x4*>(wr + q * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(&tile[lane * PS + q * 4]) = acc[q];
+        // the wave's own patch: its LDS operations execute in order, no barrier
+        const int npx = min(64, p1 - base);
+        float* const orow = out + ((size_t)b * HW + base) * COUT;
+#pragma unroll
+        for (int r = 0; r < NQ; ++r) {
+            const int idx = r * 64 + lane;
+            const int px = idx / NQ, c = idx - px * NQ;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(&tile[px * PS + c * 4]);
+            if (px < npx) {
+#if defined(PW_ABL) && PW_ABL == 5      // ablation: no output stores
+                if (val[0] == 12345.678f)
+#endif
+                *reinterpret_cast<f32x4*>(orow + (size_t)idx * 4) = val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ssum[r % SETS][e] += val[e]; ssq[r % SETS][e] += val[e] * val[e]; }
+            }
+        }
+    }
+    if (tot == nullptr) return;
+#if defined(PW_ABL) && PW_ABL == 8      // ablation: sums accumulated, never published
+    if (ssum[0][0] != 12345.678f) return;
+#endif
+    // statistics: scratch [2][COUT][SLOTS]; contributor (wave, set j, lane) of quad (lane + 64 j) % NQ sits in slot (wave * SETS + j) * ceil(64 / NQ) + lane / NQ
+    __syncthreads();                          // every wave is done with its tile
+    float* const scratch = ic1_lds;
+    for (int i = tid; i < 2 * COUT * SLOTS; i += 256) scratch[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SETS; ++j) {
+        const int quad = (lane + 64 * j) % NQ;
+        const int slot = (wave * SETS + j) * ((64 + NQ - 1) / NQ) + lane / NQ;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            scratch[(size_t)(quad * 4 + e) * SLOTS + slot] = ssum[j][e];
+            scratch[(size_t)(COUT + quad * 4 + e) * SLOTS + slot] = ssq[j][e];
+        }
+    }
+    auto fold = [&](int i) {
+        double t = 0;
+        for (int l = 0; l < SLOTS; ++l) t += (double)scratch[(size_t)i * SLOTS + l];
+        return (float)t;
+    };
+    stat_word* const acc_lds = reinterpret_cast<stat_word*>(ic1_lds + 4 * 64 * PS);
+    stat_publish(tot, b, COUT, bs, rep, blockIdx.x % rep, 0, COUT, fold, acc_lds, tid, 256);
+}
+
+template <int COUT>
+static hipError_t in_conv1_launch(const float* x, const float* cond, const float* w, const float* bias, float* out,
+                                  stat_word* tot, int rep, int bs, int B, int H, int W, hipStream_t s) {
+#ifndef IC1_PASSES
+#define IC1_PASSES 2
+#endif
+    const int HW = H * W;
+    int per = IC1_PASSES * 256;             // pixels per workgroup (4 waves x 64 pixels per pass), at most 1024 workgroups per sample
+    while ((HW + per - 1) / per > 1024) per += 256;
+    const int rows = (HW + per - 1) / per;
+    constexpr int NQ = COUT / 4, PS = COUT + 4;
+    constexpr int G64 = (NQ % 16 == 0) ? 16 : (NQ % 8 == 0) ? 8 : (NQ % 4 == 0) ? 4 : (NQ % 2 == 0) ? 2 : 1;
+    constexpr int SLOTS = 4 * (NQ / G64) * ((64 + NQ - 1) / NQ);
+    static_assert(2 * COUT * SLOTS <= 4 * 64 * PS, "the statistics scratch aliases the tiles");
+    const size_t lds = (size_t)4 * 64 * PS * sizeof(float) + (size_t)(COUT + 2) * STAT_WORDS * sizeof(stat_word) + 16;
+    hipLaunchKernelGGL(in_conv1_kernel<COUT>, dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, H, W, per);
+    return hipGetLastError();
+}
+
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w, const float* bias, float* out,
                           stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, hipStream_t s) {
     if (Cout % 16 || Cout / 16 > 256) return hipErrorInvalidValue;
+    if (ic == 1) {                          // the grayscale case: in_conv1_kernel for the widths it is instantiated for
+        if (Cout == 48) return in_conv1_launch<48>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
+        if (Cout == 32) return in_conv1_launch<32>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
+        if (Cout == 64) return in_conv1_launch<64>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
+    }
     const int ppi = 256 / (Cout / 16);
     const int rows = pointwise_rows(H * W, ppi);
     const size_t lds = (size_t)(9 * 2 * ic * Cout + Cout + 2 * Cout * ppi + 2) * sizeof(float) + (size_t)(Cout + 2) * STAT_WORDS * sizeof(stat_word);
@@ -131,40 +295,78 @@ constexpr int OC_T = 16;
 constexpr int OC_I = OC_T + 2;
 constexpr int OC_PS = 20;         // padded pixel stride in floats
 
+// IC: output channels at compile time (1: the reference's grayscale case; 0: a.ic at run time, <= 4).  With the count
+// only known at run time hipcc indexes the accumulators through select chains and splits the 16-byte LDS reads:
+// 7 340 instructions, 989 v_cndmask among them, for a loop of 432 multiply-adds (round 3; tools/isa_count.py).
+template <int IC>
 __global__ __launch_bounds__(256)
-void out_conv_kernel(const OutConvArgs a) {
-    __shared__ float tile[OC_I * OC_I * OC_PS];
-    extern __shared__ float wl[];                 // [ic][9][C], then [2][C] GroupNorm scale / shift of this sample
+void out_conv_kernel(const OutConvArgs a, const float* __restrict__ wglob /* == a.w: a restrict parameter of its own, so that uniform reads become scalar loads */) {
+    __shared__ __attribute__((aligned(16))) float tile[OC_I * OC_I * OC_PS];
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [ic][9][C], then [2][C] GroupNorm scale / shift of this sample
+    const int ic = IC ? IC : a.ic;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    float* const gnp = wl + a.ic * 9 * a.C;
+    float* const gnp = wl + ic * 9 * a.C;
     const int tiles_x = (a.W + OC_T - 1) / OC_T, tiles_y = (a.H + OC_T - 1) / OC_T;
     const int b = blockIdx.x / (tiles_x * tiles_y);
     const int trem = blockIdx.x - b * tiles_x * tiles_y;
     const int oy0 = (trem / tiles_x) * OC_T, ox0 = (trem % tiles_x) * OC_T;
     const int C = a.C;
-    for (int i = tid; i < a.ic * 9 * C; i += 256) wl[i] = a.w[i];
+    if constexpr (IC == 0) for (int i = tid; i < ic * 9 * C; i += 256) wl[i] = a.w[i];     // (IC > 0 reads the weights through scalar loads)
     // (second source: C1 = 0, never read; a literal nullptr there crashes hipcc 7.2's inliner)
     gn_prologue_lds(a.gn_tot, C, a.gn_bs, a.gn_tot, 0, 1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, 1.0 / ((double)a.H * a.W * (C / GN_GROUPS_C)), b, 1.0f, gnp, tid, 256);
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};          // ic <= 4 output channels
+    // Staging, round 3: a thread's slots (halo pixel, channel quad) are the same for every 16-channel chunk, so their
+    // addresses are formed once, branch-free (clamped; out-of-image and surplus slots load a valid dummy and store
+    // zeros), and the NEXT chunk's quads are requested before this chunk's taps: the loads fly under the arithmetic.
+    constexpr int NSL = (OC_I * OC_I * 4 + 255) / 256;
+    unsigned soff[NSL];                           // float offset of the slot's quad in channel block 0
+    unsigned live = 0;                            // bit s: slot exists and lies in the image
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+        const int slot = min(tid + s * 256, OC_I * OC_I * 4 - 1);
+        const int pix = slot >> 2, q = slot & 3;
+        const int iy = pix / OC_I, ix = pix - iy * OC_I;
+        const int gy = oy0 + iy - 1, gx = ox0 + ix - 1;
+        const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+        if (tid + s * 256 < OC_I * OC_I * 4 && gy == cy && gx == cx) live |= 1u << s;
+        soff[s] = (unsigned)(((size_t)(b * a.H + cy) * a.W + cx) * C + q * 4);
+    }
+    f32x4 pre[NSL];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+#if defined(PW_ABL) && PW_ABL == 11     // ablation (tools/mb/pw_abl.hip, wrong results): no input loads
+            pre[s] = (f32x4){(float)soff[s], 1.f, 2.f, 3.f};
+#else
+            pre[s] = *reinterpret_cast<const f32x4*>(a.src + soff[s] + c0);
+#endif
+        }
+    };
+    prefetch(0);
     for (int c0 = 0; c0 < C; c0 += 16) {
-        __syncthreads();
-        for (int slot = tid; slot < OC_I * OC_I * 4; slot += 256) {
-            const int pix = slot >> 2, q = slot & 3;
-            const int iy = pix / OC_I, ix = pix - iy * OC_I;
-            const int gy = oy0 + iy - 1, gx = ox0 + ix - 1;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                v = *reinterpret_cast<const f32x4*>(a.src + ((size_t)(b * a.H + gy) * a.W + gx) * C + c0 + q * 4);
+        __syncthreads();                          // the previous chunk's taps are done with the tile
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            const int slot = tid + s * 256;
+            if (slot < OC_I * OC_I * 4) {
+                const int q = slot & 3;
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(gnp + c0 + q * 4);
                 const f32x4 sh = *reinterpret_cast<const f32x4*>(gnp + C + c0 + q * 4);
-                v = v * sc + sh;
+                f32x4 v = pre[s] * sc + sh;
+#if !(defined(PW_ABL) && PW_ABL == 12)  // ablation: no SiLU
                 v.x = silu_pw(v.x); v.y = silu_pw(v.y); v.z = silu_pw(v.z); v.w = silu_pw(v.w);
+#endif
+                if (!((live >> s) & 1u)) v = (f32x4){0.f, 0.f, 0.f, 0.f};      // the conv's zero padding
+                *reinterpret_cast<f32x4*>(&tile[(slot >> 2) * OC_PS + q * 4]) = v;
             }
-            *reinterpret_cast<f32x4*>(&tile[pix * OC_PS + q * 4]) = v;
         }
+        if (c0 + 16 < C) prefetch(c0 + 16);
         __syncthreads();
+#if defined(PW_ABL) && PW_ABL == 13     // ablation: no taps
+        acc[0] += tile[(ty * OC_I + tx) * OC_PS];
+#else
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -172,17 +374,29 @@ void out_conv_kernel(const OutConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(px + q * 4);
-                for (int oc = 0; oc < a.ic; ++oc) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[(oc * 9 + tap) * C + c0 + q * 4]);
-                    acc[oc] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                if constexpr (IC > 0) {
+#pragma unroll
+                    for (int oc = 0; oc < IC; ++oc) {
+                        // uniform address: scalar loads, the weights are SGPR operands (no LDS read, no register)
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wglob + (((oc * 9 + tap) * (C >> 4)) << 4) + c0 + q * 4);
+                        acc[oc] = __builtin_fmaf(v.x, wv.x, __builtin_fmaf(v.y, wv.y, __builtin_fmaf(v.z, wv.z, __builtin_fmaf(v.w, wv.w, acc[oc]))));
+                    }
+                } else {
+                    for (int oc = 0; oc < ic; ++oc) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(&wl[(oc * 9 + tap) * C + c0 + q * 4]);
+                        acc[oc] += v.x * wv.x + v.y * wv.y + v.z * wv.z + v.w * wv.w;
+                    }
                 }
             }
         }
+#endif
     }
     const int oy = oy0 + ty, ox = ox0 + tx;
     if (oy >= a.H || ox >= a.W) return;
-    for (int oc = 0; oc < a.ic; ++oc) {
-        const size_t o = (((size_t)b * a.ic + oc) * a.H + oy) * a.W + ox;
+#pragma unroll
+    for (int oc = 0; oc < (IC ? IC : 4); ++oc) {
+        if (oc >= ic) break;
+        const size_t o = (((size_t)b * ic + oc) * a.H + oy) * a.W + ox;
         float eps = acc[oc] + a.bias[oc];
         if (a.eps_out) a.eps_out[o] = eps;
         if (a.x) {
@@ -202,7 +416,8 @@ hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s) {
     if (a.ic > 4 || a.C % 16) return hipErrorInvalidValue;
     const size_t lds = ((size_t)a.ic * 9 * a.C + 2 * a.C) * sizeof(float);
     const int tiles = ((a.W + OC_T - 1) / OC_T) * ((a.H + OC_T - 1) / OC_T);
-    hipLaunchKernelGGL(out_conv_kernel, dim3(a.B * tiles), dim3(256), lds, s, a);
+    if (a.ic == 1) hipLaunchKernelGGL(out_conv_kernel<1>, dim3(a.B * tiles), dim3(256), lds, s, a, a.w);
+    else hipLaunchKernelGGL(out_conv_kernel<0>, dim3(a.B * tiles), dim3(256), lds, s, a, a.w);
     return hipGetLastError();
 }
 

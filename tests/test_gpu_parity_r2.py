@@ -365,7 +365,7 @@ def test_launched_kernels():
     prof = model.profile_end()
     names = {p["name"].split("<")[0] for p in prof}
     print(sorted(names), sum(p["launches"] for p in prof), "launches")
-    assert names == {"midd::in_conv_kernel", "midd::conv_mfma_f16x3_kernel", "midd::conv1x1_f16x3_kernel",
+    assert names == {"midd::in_conv1_kernel", "midd::conv_mfma_f16x3_kernel", "midd::conv1x1_f16x3_kernel",
                      "midd::attention_f16x3_kernel", "midd::resize_bilinear_kernel", "midd::out_conv_kernel"}
     # 143 in round 1: 51 GroupNorm finalize launches and 4 statistics passes (now in the producers' epilogues) are gone;
     # 100 in round 2 (88 ops, an attention op being prep + attention + combine); round 3: every op is ONE launch, the 15
