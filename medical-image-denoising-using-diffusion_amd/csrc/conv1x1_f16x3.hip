@@ -86,11 +86,19 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
         const float* src; int cs;
         int ch = step * 32 + kq * 8;
         if (ch >= Cin) ch = Cin - 8;                          // trailing half step: valid dummy, zeroed in transform
-        if (ch < a.C0) { src = a.src0 + ch; cs = a.C0; } else { src = a.src1 + (ch - a.C0); cs = a.C1; }
+        size_t pstride;                                       // floats between two pixels of the lane's 8-channel group
+        if constexpr (ATT == ATT_PART_IN) {                   // the attention kernel's partials: [split][B][N][C], pixel-major
+            src = a.src0 + ch + img0 * Cin; pstride = (size_t)Cin; cs = Cin;
+        } else {                                              // channel-blocked activations [B][C/16][HW][16] (midd_internal.h)
+            int nb, cc;
+            if (ch < a.C0) { src = a.src0; nb = a.C0 >> 4; cc = ch; } else { src = a.src1; nb = a.C1 >> 4; cc = ch - a.C0; }
+            src += ((size_t)(b * nb + (cc >> 4)) * HW) * 16 + (cc & 15); pstride = 16; cs = 0;
+        }
+        (void)cs;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = min(tile * BM + (wave * MT + mt) * 16 + p16, HW - 1);
-            const float* q = src + (img0 + p) * cs;
+            const float* q = src + (size_t)p * pstride;
 #pragma unroll
             for (int g = 0; g < SG; ++g) {
                 const float* qg = q + (size_t)min(g, (ATT == ATT_PART_IN ? a.att_ksplit : 1) - 1) * split_stride;      // missing splits: a valid duplicate, coefficient 0
@@ -223,7 +231,7 @@ void conv1x1_f16x3_kernel(const ConvArgs a) {
                 for (int mt = 0; mt < MT; ++mt) {
                     const int p = tile * BM + (wave * MT + mt) * 16 + p16;
                     if (p < HW) {
-                        const size_t o = (img0 + p) * a.Cout + co;
+                        const size_t o = (((size_t)b * (a.Cout >> 4) + (co >> 4)) * HW + p) * 16 + (co & 15);      // channel-blocked output / residual
                         f32x4 v = acc[mt][nt] * oscale + add;
                         if (a.resid != nullptr) v += *reinterpret_cast<const f32x4*>(a.resid + o);
                         *reinterpret_cast<f32x4*>(a.out + o) = v;
@@ -389,7 +397,7 @@ bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t) {
 }
 
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
-    if (a.C0 % 8 || a.C1 % 8) return hipErrorInvalidValue;  // an 8-channel lane group must not straddle the concat seam
+    if (a.C0 % 16 || a.C1 % 16) return hipErrorInvalidValue;  // whole 16-channel blocks per source (channel-blocked activations)
     if (a.att_mode != ATT_NONE) {
         // the hand-off's geometry: heads x D channels, D a multiple of 32 (a K step / a 16-channel tile stays inside one head)
         if (a.att_D % 32 || a.att_heads != 2 || a.att_ksplit > C1_MAX_SPLIT) return hipErrorInvalidValue;

@@ -189,7 +189,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // ---- activations: per-thread slots (halo pixel, 4-channel quad q8 of the 32-channel chunk) ----
     const int q8 = tid % QPP;                             // (NTHREADS % QPP == 0: constant per thread)
     const int sblk = q8 >> 2;
-    int g_off[APW];            // pixel index into the image; -1: out of the image; -2: slot beyond the tile
+    int g_off[APW];            // pixel index inside the sample's image; -1: out of the image; -2: slot beyond the tile
     bool tile_pad = true;      // (uniform) the tile's halo leaves the image somewhere: only then a slot can be out of the image
     auto set_tile = [&](int t) {
         const int iy0 = (t / a.tiles_x) * TH * STRIDE - PAD, ix0 = (t % a.tiles_x) * TW * STRIDE - PAD;
@@ -202,7 +202,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 const int pix = slot / QPP;
                 const int iy = pix / IW, ix = pix - iy * IW;
                 const int gy = iy0 + iy, gx = ix0 + ix;
-                off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (b * a.H + gy) * a.W + gx : -1;
+                off = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? gy * a.W + gx : -1;
             }
             g_off[s] = off;
         }
@@ -211,15 +211,15 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // Lanes with nothing to fetch (padding, unused slots, missing second block) read a valid
     // dummy address; transform() writes zeros / nothing for them.
     auto issue_a = [&](int c) {
+        // channel-blocked activations [B][C/16][H][W][16]: the chunk's 16-channel block of a halo row is one contiguous run
         const int blk = min(CB * c + sblk, nblk - 1);
-        const int ch = (blk << 4) + (q8 & 3) * 4;
-        const float* src; unsigned cs4, coff;
-        if (ch < a.C0) { src = a.src0; cs4 = a.C0 * 4u; coff = ch * 4u; }
-        else           { src = a.src1; cs4 = a.C1 * 4u; coff = (ch - a.C0) * 4u; }
-        const char* base = reinterpret_cast<const char*>(src);
+        const float* src; int bsrc, nb;
+        if ((blk << 4) < a.C0) { src = a.src0; bsrc = blk; nb = a.C0 >> 4; }
+        else                   { src = a.src1; bsrc = blk - (a.C0 >> 4); nb = a.C1 >> 4; }
+        const char* base = reinterpret_cast<const char*>(src) + ((size_t)(b * nb + bsrc) * (size_t)(a.H * a.W)) * 64 + (q8 & 3) * 16;
 #pragma unroll
         for (int s = 0; s < APW; ++s) {
-            const unsigned byte_off = (unsigned)max(g_off[s], 0) * cs4 + coff;      // tensors are < 4 GiB (host-checked)
+            const unsigned byte_off = (unsigned)max(g_off[s], 0) * 64u;             // one block plane is < 4 GiB (host-checked)
             dma16(base + byte_off, raw + (wave + s * NW) * 1024);
         }
     };
@@ -466,14 +466,15 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         const int rc = a.res_C0 + a.res_C1;
         int ch = r * 32 + kq * 8;
         if (ch >= rc) ch = rc - 8;                        // trailing half step: valid dummy, meets zero weights
-        const float* src; int cs;
-        if (ch < a.res_C0) { src = a.res_src0 + ch; cs = a.res_C0; } else { src = a.res_src1 + (ch - a.res_C0); cs = a.res_C1; }
+        const float* src; int nb, cc;               // 8 channels inside one 16-channel block of the blocked layout
+        if (ch < a.res_C0) { src = a.res_src0; nb = a.res_C0 >> 4; cc = ch; } else { src = a.res_src1; nb = a.res_C1 >> 4; cc = ch - a.res_C0; }
+        src += ((size_t)(b * nb + (cc >> 4)) * (size_t)(a.OH * a.OW)) * 16 + (cc & 15);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int pp = (wm * MT + mt) * 16 + p16;
             const int py = pp / TW, px = pp - py * TW;
             const int oy = min(oy0 + py, a.OH - 1), ox = min(ox0 + px, a.OW - 1);
-            const float* q = src + ((size_t)(b * a.OH + oy) * a.OW + ox) * cs;
+            const float* q = src + (size_t)(oy * a.OW + ox) * 16;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst[mt][0]) : "v"(q) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(dst[mt][1]) : "v"(q) : "memory");
         }
@@ -580,20 +581,22 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         f32x4 rres[MT][NT];
         size_t obase[MT];
         bool rowok[MT];
+        const size_t ohw = (size_t)a.OH * a.OW;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int pp = (wm * MT + mt) * 16 + p16;
             const int py = pp / TW, px = pp - py * TW;
             const int oy = oy0 + py, ox = ox0 + px;
             rowok[mt] = oy < a.OH && ox < a.OW;
-            obase[mt] = ((size_t)(b * a.OH + min(oy, a.OH - 1)) * a.OW + min(ox, a.OW - 1)) * a.Cout + ntile0 * 16 + kq * 4;
+            // blocked output [B][Cout/16][OH][OW][16]: the 16 pixel lanes x 4 cout quads of an MFMA tile write one contiguous KiB
+            obase[mt] = (((size_t)b * (a.Cout >> 4) + ntile0) * ohw + (size_t)(min(oy, a.OH - 1) * a.OW + min(ox, a.OW - 1))) * 16 + kq * 4;
         }
         if (a.resid != nullptr) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)       // (rows beyond the image: a valid, clamped address; never stored)
-                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rres[mt][nt]) : "v"(a.resid + obase[mt] + nt * 16) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rres[mt][nt]) : "v"(a.resid + obase[mt] + nt * ohw * 16) : "memory");
             // one statement names every destination: nothing that uses (or copies) them can be scheduled above the wait
             if constexpr (MT == 2 && NT == 3) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[0][2]), "+v"(rres[1][0]), "+v"(rres[1][1]), "+v"(rres[1][2]) :: "memory");
             else if constexpr (MT == 2 && NT == 2) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[1][0]), "+v"(rres[1][1]) :: "memory");
@@ -610,7 +613,7 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
                     f32x4 v = acc[mt][nt] * oscale + add;
                     if (a.resid != nullptr) v += rres[mt][nt];
-                    *reinterpret_cast<f32x4*>(a.out + obase[mt] + nt * 16) = v;
+                    *reinterpret_cast<f32x4*>(a.out + obase[mt] + nt * ohw * 16) = v;
 #if !(defined(C16_ABL) && C16_ABL == 1)  // ablation 1 (wrong results): no statistics of the output
                     ssum[nt] += v; ssq[nt] += v * v;
 #endif
@@ -802,7 +805,7 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
                 raised = lds_bytes;
             }
         }
-        if ((double)a.B * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets
+        if ((double)a.H * a.W * 64.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets inside one block plane
         hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES, CBT>), grid, dim3(G::NTHREADS), lds_bytes, s, a);
         return hipGetLastError();
     } else {

@@ -17,7 +17,7 @@ constexpr int GN_THREADS = 256;
 // grid (rows, B): block `row` sums a contiguous pixel range of sample b per channel in fp64 (products of fp32 values
 // are exact in fp64), rounds the block's sums to fp32 and adds them to the totals with exact integer atomics (stats_common.h).
 __global__ __launch_bounds__(GN_THREADS)
-void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int rep, int bs, int HW, int C, int rows) {
+void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ tot, int rep, int bs, int HW, int C, int rows, int blocked) {
     extern __shared__ double red[];               // [ppi][C][2] doubles, then the block accumulators of stat_publish
     const int CQ = C >> 2;
     const int ppi = GN_THREADS / CQ;
@@ -28,9 +28,8 @@ void chan_total_kernel(const float* __restrict__ src, stat_word* __restrict__ to
     const int p0 = row * per, p1 = min(HW, p0 + per);
     if (pl < ppi) {
         double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-        const float* base = src + (size_t)b * HW * C + q * 4;
         for (int p = p0 + pl; p < p1; p += ppi) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + act_index(blocked, b, C, HW, p, q * 4));
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; ss[e] = fma(d, d, ss[e]); }
         }
@@ -58,11 +57,11 @@ int chan_partial_rows(int HW, int C) {
     return r;
 }
 
-hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, hipStream_t s) {
+hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, int blocked, hipStream_t s) {
     if (C % 4 || C / 4 > GN_THREADS) return hipErrorInvalidValue;
     const int ppi = GN_THREADS / (C / 4);
     const size_t lds = (size_t)ppi * C * 2 * sizeof(double) + (size_t)(C + 2) * STAT_WORDS * sizeof(stat_word);
-    hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, tot, rep, bs, HW, C, rows);
+    hipLaunchKernelGGL(chan_total_kernel, dim3(rows, B), dim3(GN_THREADS), lds, s, src, tot, rep, bs, HW, C, rows, blocked);
     return hipGetLastError();
 }
 

@@ -958,6 +958,8 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* 
     auto T = [&](size_t off) { return reinterpret_cast<stat_word*>(ws + off); };
     // every tensor's GroupNorm totals start the forward at zero (producers accumulate with atomics)
     if (hipMemsetAsync(ws + g->stats_off, 0, g->stats_bytes, s) != hipSuccess) return fail(MI_EHIP, "clearing the statistics arena failed");
+    // split-fp16 plans keep their activations channel-blocked, [B][C/16][H][W][16] (midd_internal.h); fp32-MFMA plans NHWC
+    const int blocked = p->cfg.compute_mode == MI_COMPUTE_F16X3 ? 1 : 0;
     for (const Op& o : g->ops) {
         hipError_t e = hipSuccess;
         hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -975,10 +977,10 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* 
         switch (o.kind) {
             case OP_IN_CONV:
                 e = in_conv_launch(io.x, io.cond, wd + p->w_in, wd + p->b_in, F(o.dst.off), T(o.dst.tot_off), g->stat_rep, o.dst.stat_bs,
-                                   B, p->cfg.in_channels, g->H, g->W, o.dst.C, s);
+                                   B, p->cfg.in_channels, g->H, g->W, o.dst.C, blocked, s);
                 break;
             case OP_CHAN_TOT:
-                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), g->stat_rep, o.s0.stat_bs, B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, s);
+                e = chan_total_launch(F(o.s0.off), T(o.s0.tot_off), g->stat_rep, o.s0.stat_bs, B, o.s0.H * o.s0.W, o.s0.C, o.stat_rows, blocked, s);
                 break;
             case OP_CONV: {
                 ConvArgs a{};
@@ -1033,14 +1035,14 @@ static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* 
                 }
                 break;
             case OP_RESIZE:
-                e = resize_bilinear_launch(F(o.s0.off), F(o.dst.off), T(o.dst.tot_off), g->stat_rep, o.dst.stat_bs, B, o.s0.H, o.s0.W, o.s0.C, o.dst.H, o.dst.W, s);
+                e = resize_bilinear_launch(F(o.s0.off), F(o.dst.off), T(o.dst.tot_off), g->stat_rep, o.dst.stat_bs, B, o.s0.H, o.s0.W, o.s0.C, o.dst.H, o.dst.W, blocked, s);
                 break;
             case OP_CONVT:
-                e = conv_transpose_launch(F(o.s0.off), wd + o.w, wd + o.b, F(o.dst.off), B, o.s0.H, o.s0.W, o.s0.C, o.dst.C, s);
+                e = conv_transpose_launch(F(o.s0.off), wd + o.w, wd + o.b, F(o.dst.off), B, o.s0.H, o.s0.W, o.s0.C, o.dst.C, blocked, s);
                 break;
             case OP_OUT: {
                 OutConvArgs a{};
-                a.src = F(o.s0.off); a.gn_tot = T(o.s0.tot_off); a.stat_rep = g->stat_rep; a.gn_bs = o.s0.stat_bs; a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
+                a.src = F(o.s0.off); a.blocked = blocked; a.gn_tot = T(o.s0.tot_off); a.stat_rep = g->stat_rep; a.gn_bs = o.s0.stat_bs; a.gn_gamma = wd + o.gn.gamma; a.gn_beta = wd + o.gn.beta; a.gn_eps = 1e-5f;
                 a.w = wd + p->w_out; a.bias = wd + p->b_out;
                 a.B = B; a.H = g->H; a.W = g->W; a.C = o.s0.C; a.ic = p->cfg.in_channels;
                 a.eps_out = io.eps_out; a.x = io.x_update; a.noise = io.noise;
@@ -1223,7 +1225,8 @@ extern "C" int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int
     if (C) *C = t.C; if (h) *h = t.H; if (w) *w = t.W;
     if (dst) {
         if (!workspace) return fail(MI_EINVAL, "null workspace");
-        hipError_t e = nhwc_to_nchw_launch(reinterpret_cast<const float*>((const char*)workspace + t.off), dst, B, t.H, t.W, t.C, (hipStream_t)stream);
+        hipError_t e = nhwc_to_nchw_launch(reinterpret_cast<const float*>((const char*)workspace + t.off), dst, B, t.H, t.W, t.C,
+                                           plan->cfg.compute_mode == MI_COMPUTE_F16X3 ? 1 : 0, (hipStream_t)stream);
         if (e != hipSuccess) return fail(MI_EHIP, "nhwc_to_nchw: %s", hipGetErrorString(e));
     }
     return MI_OK;

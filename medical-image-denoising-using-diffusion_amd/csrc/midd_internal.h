@@ -1,6 +1,14 @@
 // Internal declarations shared by the HIP kernels and the C-ABI host side of libmidd.so.
-// Activations inside the library are fp32 NHWC ([B][H][W][C]); only the boundary tensors
-// ([B,in_channels,H,W], in_channels == 1 in every reference call site) are NCHW.
+// Activations inside the library are fp32, channels innermost; only the boundary tensors ([B,in_channels,H,W],
+// in_channels == 1 in every reference call site) are NCHW.  Two layouts:
+//   fp32-MFMA plans   NHWC            [B][H][W][C]
+//   split-fp16 plans  CHANNEL-BLOCKED [B][C/16][H][W][16]   (round 3)
+// The f16x3 kernels stage a K chunk of 16 channels at a time.  In NHWC a chunk is 64 bytes of every pixel's C*4-byte row: L2
+// fetches whole 128-byte lines, a chunk pass touches 2/3 of the tensor's lines (C = 48), three passes fetch it twice --
+// measured (rocprofv3 FETCH_SIZE calibrated on this very pattern, tools/mb/fetch_calib.hip): 63 MB per launch of the
+// dominant kernel for 33 MB of operands; the L2 of an XCD turns over several times between two chunk passes of a tile.
+// Blocked, a chunk of a halo row is one contiguous run, every fetched line is used whole, and a 16-pixel x 16-cout MFMA
+// tile leaves as ONE contiguous KiB instead of sixteen 64-byte pieces.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,9 +19,14 @@ namespace midd {
 // ---------------------------------------------------------------- implicit-GEMM convolution
 enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
 
-struct ConvArgs {
-    const float* src0;      // NHWC, C0 channels
-    const float* src1;      // NHWC, C1 channels (virtual torch.cat on dim=1); may be null when C1 == 0
+// element index of (sample b, pixel pix, channel ch) in an activation tensor of C channels and HW pixels per sample
+__host__ __device__ inline size_t act_index(int blocked, int b, int C, int HW, int pix, int ch) {
+    return blocked ? (((size_t)b * (C >> 4) + (ch >> 4)) * HW + pix) * 16 + (ch & 15) : ((size_t)b * HW + pix) * C + ch;
+}
+
+struct ConvArgs {          // (activation pointers: NHWC for the fp32-MFMA kernels, channel-blocked for the f16x3 kernels)
+    const float* src0;      // C0 channels
+    const float* src1;      // C1 channels (virtual torch.cat on dim=1); may be null when C1 == 0
     int C0, C1;
     int B, H, W;            // input spatial size
     int OH, OW;             // output spatial size
@@ -111,7 +124,7 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps, int cb = 0) {
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
 // per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
 // sample each add their partial sums to tot [B][C/bs][rep][2][3]
-hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, hipStream_t s);
+hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, int blocked, hipStream_t s);
 int chan_partial_rows(int HW, int C);
 
 // ---------------------------------------------------------------- pre/post-processing (prepost.hip)
@@ -141,10 +154,11 @@ bool attention_supported(int head_dim);
 // in_conv: Conv3x3 on cat[x, cond] (NCHW [B,ic,H,W] each) -> NHWC [B][H][W][Cout]
 // tot != nullptr: also leaves the GroupNorm totals of the output [B][Cout/bs][rep][2][3] (stats_common.h)
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9][2ic][Cout]*/, const float* bias,
-                          float* out, stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, hipStream_t s);
+                          float* out, stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, int blocked, hipStream_t s);
 
 struct OutConvArgs {
-    const float* src;       // NHWC [B][H][W][C]
+    const float* src;       // [B][H][W][C], or channel-blocked [B][C/16][H][W][16] when `blocked`
+    int blocked;
     const stat_word* gn_tot; int stat_rep, gn_bs; const float* gn_gamma; const float* gn_beta; float gn_eps;   // GroupNorm of src: totals [B][C/bs][rep][2][3], affine [C]
     const float* w;         // [ic][9][C]
     const float* bias;      // [ic]
@@ -159,12 +173,12 @@ struct OutConvArgs {
 hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s);
 
 // bilinear resize NHWC (align_corners=False), any size ratio
-hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, hipStream_t s);
+hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, int blocked, hipStream_t s);
 // ConvTranspose2d(C,C,4,stride=2,padding=1) direct (only used by topologies where it cannot be folded)
 hipError_t conv_transpose_launch(const float* src, const float* w /*[4][4][Cin][Cout]*/, const float* bias, float* dst,
-                                 int B, int H, int W, int Cin, int Cout, hipStream_t s);
+                                 int B, int H, int W, int Cin, int Cout, int blocked, hipStream_t s);
 // NHWC -> NCHW copy (debug fetch)
-hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, hipStream_t s);
+hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, int blocked, hipStream_t s);
 hipError_t fill_i32_launch(int* dst, const int* host_vals, int n, hipStream_t s);
 
 }  // namespace midd

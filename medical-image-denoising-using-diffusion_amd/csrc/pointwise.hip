@@ -29,12 +29,13 @@ __device__ __forceinline__ float silu_pw(float v) {
 template <int NV>
 __device__ __forceinline__ void pointwise_publish(const float (&sum)[NV], const float (&sq)[NV], bool active, int pl, int ppi, int cgrp,
                                                   int C, float* scratch, stat_word* acc, stat_word* tot, int b, int bs, int rep,
-                                                  int replica, int tid, int nthreads = 256) {
+                                                  int replica, int tid, int nthreads = 256, int c0 = 0, int ncol = -1) {
+    if (ncol < 0) ncol = C;                       // the workgroup's channels: [c0, c0 + ncol) of the tensor's C; cgrp counts inside them
     if (active) {
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
             scratch[(size_t)(cgrp * NV + e) * ppi + pl] = sum[e];
-            scratch[(size_t)(C + cgrp * NV + e) * ppi + pl] = sq[e];
+            scratch[(size_t)(ncol + cgrp * NV + e) * ppi + pl] = sq[e];
         }
     }
     auto fold = [&](int i) {
@@ -42,7 +43,7 @@ __device__ __forceinline__ void pointwise_publish(const float (&sum)[NV], const 
         for (int l = 0; l < ppi; ++l) t += (double)scratch[(size_t)i * ppi + l];
         return (float)t;
     };
-    stat_publish(tot, b, C, bs, rep, replica, 0, C, fold, acc, tid, nthreads);
+    stat_publish(tot, b, C, bs, rep, replica, c0, ncol, fold, acc, tid, nthreads);
 }
 
 // pixels a workgroup of 256 threads walks: ~4 per pixel lane, at most 1024 workgroups per sample
@@ -57,7 +58,7 @@ static int pointwise_rows(int HW, int ppi) {
 __global__ __launch_bounds__(256)
 void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ w,
                     const float* __restrict__ bias, float* __restrict__ out, stat_word* __restrict__ tot, int rep, int bs,
-                    int ic, int H, int W, int Cout, int rows) {
+                    int ic, int H, int W, int Cout, int rows, int blocked) {
     extern __shared__ float wl[];                 // 9*2ic*Cout + Cout, then the statistics scratch
     const int nw = 9 * 2 * ic * Cout;
     for (int i = threadIdx.x; i < nw + Cout; i += 256) wl[i] = (i < nw) ? w[i] : bias[i - nw];
@@ -111,7 +112,7 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
 #if defined(PW_ABL) && PW_ABL == 1      // ablation: no output stores
                 if (acc[k][0] == 12345.678f)
 #endif
-                *reinterpret_cast<f32x4*>(out + ((size_t)b * HW + p) * Cout + cg * 16 + k * 4) = acc[k];
+                *reinterpret_cast<f32x4*>(out + act_index(blocked, b, Cout, HW, p, cg * 16 + k * 4)) = acc[k];
 #if !(defined(PW_ABL) && PW_ABL == 2)   // ablation: no statistics
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { ssum[k * 4 + e] += acc[k][e]; ssq[k * 4 + e] += acc[k][e] * acc[k][e]; }
@@ -137,16 +138,18 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
 //   leaves as whole contiguous rows, every lane 16 bytes next to its neighbour's;
 //   the statistics are summed on the values in store order: a lane meets NQ / gcd(64, NQ) different channel quads.
 // Same accumulation order per output as above: bias, then (channel, dy, dx).  grid (rows, B), 4 waves.
-template <int COUT>
+template <int COUT, bool BLOCKED>
 __global__ __launch_bounds__(256, 3)
 void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ w,
                      const float* __restrict__ bias, float* __restrict__ out, stat_word* __restrict__ tot, int rep, int bs,
                      int H, int W, int per) {
     constexpr int NQ = COUT / 4;                                  // 16-byte pieces per pixel
     constexpr int G64 = (NQ % 16 == 0) ? 16 : (NQ % 8 == 0) ? 8 : (NQ % 4 == 0) ? 4 : (NQ % 2 == 0) ? 2 : 1;   // gcd(64, NQ)
-    constexpr int SETS = NQ / G64;                                // channel quads a lane meets in store order
+    // NHWC output: store order = pixel-major quads, a lane meets NQ / gcd(64, NQ) different quads; channel-blocked output
+    // [B][COUT/16][HW][16] (BLOCKED, midd_internal.h): store order = block, pixel, quad -- a lane meets quad lane % 4 of every block
+    constexpr int SETS = BLOCKED ? COUT / 16 : NQ / G64;          // channel quads a lane meets in store order
     constexpr int PS = COUT + 4;                                  // padded pixel stride (words): 16-byte stores of 8 lanes on distinct banks
-    constexpr int SLOTS = 4 * SETS * ((64 + NQ - 1) / NQ);        // contributors per channel: (wave, set, lane / NQ)
+    constexpr int SLOTS = BLOCKED ? 64 : 4 * SETS * ((64 + NQ - 1) / NQ);   // contributors per channel: (wave, lane / 4) | (wave, set, lane / NQ)
     extern __shared__ __attribute__((aligned(16))) float ic1_lds[];   // [4 waves][64][PS] tiles; afterwards the statistics scratch [2][COUT][SLOTS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -208,19 +211,26 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
         for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(&tile[lane * PS + q * 4]) = acc[q];
         // the wave's own patch: its LDS operations execute in order, no barrier
         const int npx = min(64, p1 - base);
-        float* const orow = out + ((size_t)b * HW + base) * COUT;
 #pragma unroll
         for (int r = 0; r < NQ; ++r) {
-            const int idx = r * 64 + lane;
-            const int px = idx / NQ, c = idx - px * NQ;
+            int px, c, set; float* dst;
+            if constexpr (BLOCKED) {                              // block r / 4: 64 pixels x 64 bytes, contiguous
+                const int k = r >> 2, idx = (r & 3) * 64 + lane;
+                px = idx >> 2; c = k * 4 + (idx & 3); set = k;
+                dst = out + (((size_t)b * (COUT / 16) + k) * HW + base) * 16 + (size_t)idx * 4;
+            } else {
+                const int idx = r * 64 + lane;
+                px = idx / NQ; c = idx - px * NQ; set = r % SETS;
+                dst = out + ((size_t)b * HW + base) * COUT + (size_t)idx * 4;
+            }
             const f32x4 val = *reinterpret_cast<const f32x4*>(&tile[px * PS + c * 4]);
             if (px < npx) {
 #if defined(PW_ABL) && PW_ABL == 5      // ablation: no output stores
                 if (val[0] == 12345.678f)
 #endif
-                *reinterpret_cast<f32x4*>(orow + (size_t)idx * 4) = val;
+                *reinterpret_cast<f32x4*>(dst) = val;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ssum[r % SETS][e] += val[e]; ssq[r % SETS][e] += val[e] * val[e]; }
+                for (int e = 0; e < 4; ++e) { ssum[set][e] += val[e]; ssq[set][e] += val[e] * val[e]; }
             }
         }
     }
@@ -235,8 +245,8 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SETS; ++j) {
-        const int quad = (lane + 64 * j) % NQ;
-        const int slot = (wave * SETS + j) * ((64 + NQ - 1) / NQ) + lane / NQ;
+        const int quad = BLOCKED ? j * 4 + (lane & 3) : (lane + 64 * j) % NQ;
+        const int slot = BLOCKED ? wave * 16 + (lane >> 2) : (wave * SETS + j) * ((64 + NQ - 1) / NQ) + lane / NQ;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             scratch[(size_t)(quad * 4 + e) * SLOTS + slot] = ssum[j][e];
@@ -252,7 +262,7 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
     stat_publish(tot, b, COUT, bs, rep, blockIdx.x % rep, 0, COUT, fold, acc_lds, tid, 256);
 }
 
-template <int COUT>
+template <int COUT, bool BLOCKED>
 static hipError_t in_conv1_launch(const float* x, const float* cond, const float* w, const float* bias, float* out,
                                   stat_word* tot, int rep, int bs, int B, int H, int W, hipStream_t s) {
 #ifndef IC1_PASSES
@@ -264,26 +274,27 @@ static hipError_t in_conv1_launch(const float* x, const float* cond, const float
     const int rows = (HW + per - 1) / per;
     constexpr int NQ = COUT / 4, PS = COUT + 4;
     constexpr int G64 = (NQ % 16 == 0) ? 16 : (NQ % 8 == 0) ? 8 : (NQ % 4 == 0) ? 4 : (NQ % 2 == 0) ? 2 : 1;
-    constexpr int SLOTS = 4 * (NQ / G64) * ((64 + NQ - 1) / NQ);
+    constexpr int SLOTS = BLOCKED ? 64 : 4 * (NQ / G64) * ((64 + NQ - 1) / NQ);
     static_assert(2 * COUT * SLOTS <= 4 * 64 * PS, "the statistics scratch aliases the tiles");
     const size_t lds = (size_t)4 * 64 * PS * sizeof(float) + (size_t)(COUT + 2) * STAT_WORDS * sizeof(stat_word) + 16;
-    hipLaunchKernelGGL(in_conv1_kernel<COUT>, dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, H, W, per);
+    hipLaunchKernelGGL((in_conv1_kernel<COUT, BLOCKED>), dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, H, W, per);
     return hipGetLastError();
 }
 
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w, const float* bias, float* out,
-                          stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, hipStream_t s) {
+                          stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, int blocked, hipStream_t s) {
     if (Cout % 16 || Cout / 16 > 256) return hipErrorInvalidValue;
     if (ic == 1) {                          // the grayscale case: in_conv1_kernel for the widths it is instantiated for
-        if (Cout == 48) return in_conv1_launch<48>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
-        if (Cout == 32) return in_conv1_launch<32>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
-        if (Cout == 64) return in_conv1_launch<64>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
+#define MIDD_IC1(N) if (Cout == N) return blocked ? in_conv1_launch<N, true>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s) \
+                                                 : in_conv1_launch<N, false>(x, cond, w, bias, out, tot, rep, bs, B, H, W, s);
+        MIDD_IC1(48) MIDD_IC1(32) MIDD_IC1(64)
+#undef MIDD_IC1
     }
     const int ppi = 256 / (Cout / 16);
     const int rows = pointwise_rows(H * W, ppi);
     const size_t lds = (size_t)(9 * 2 * ic * Cout + Cout + 2 * Cout * ppi + 2) * sizeof(float) + (size_t)(Cout + 2) * STAT_WORDS * sizeof(stat_word);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(in_conv_kernel, dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, ic, H, W, Cout, rows);
+    hipLaunchKernelGGL(in_conv_kernel, dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, ic, H, W, Cout, rows, blocked);
     return hipGetLastError();
 }
 
@@ -321,7 +332,7 @@ void out_conv_kernel(const OutConvArgs a, const float* __restrict__ wglob /* == 
     // addresses are formed once, branch-free (clamped; out-of-image and surplus slots load a valid dummy and store
     // zeros), and the NEXT chunk's quads are requested before this chunk's taps: the loads fly under the arithmetic.
     constexpr int NSL = (OC_I * OC_I * 4 + 255) / 256;
-    unsigned soff[NSL];                           // float offset of the slot's quad in channel block 0
+    unsigned soff[NSL];                           // float offset of the slot's quad from the chunk's base
     unsigned live = 0;                            // bit s: slot exists and lies in the image
 #pragma unroll
     for (int s = 0; s < NSL; ++s) {
@@ -331,8 +342,12 @@ void out_conv_kernel(const OutConvArgs a, const float* __restrict__ wglob /* == 
         const int gy = oy0 + iy - 1, gx = ox0 + ix - 1;
         const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
         if (tid + s * 256 < OC_I * OC_I * 4 && gy == cy && gx == cx) live |= 1u << s;
-        soff[s] = (unsigned)(((size_t)(b * a.H + cy) * a.W + cx) * C + q * 4);
+        soff[s] = (unsigned)((size_t)(cy * a.W + cx) * (a.blocked ? 16 : C) + q * 4);       // inside the sample (NHWC) / inside a block plane
     }
+    const size_t plane = (size_t)a.H * a.W;
+    auto chunk_base = [&](int c0) {               // first element of the sample's 16-channel chunk c0
+        return a.blocked ? ((size_t)b * (C >> 4) + (c0 >> 4)) * plane * 16 : (size_t)b * plane * C + c0;
+    };
     f32x4 pre[NSL];
     auto prefetch = [&](int c0) {
 #pragma unroll
@@ -340,7 +355,7 @@ void out_conv_kernel(const OutConvArgs a, const float* __restrict__ wglob /* == 
 #if defined(PW_ABL) && PW_ABL == 11     // ablation (tools/mb/pw_abl.hip, wrong results): no input loads
             pre[s] = (f32x4){(float)soff[s], 1.f, 2.f, 3.f};
 #else
-            pre[s] = *reinterpret_cast<const f32x4*>(a.src + soff[s] + c0);
+            pre[s] = *reinterpret_cast<const f32x4*>(a.src + chunk_base(c0) + soff[s]);
 #endif
         }
     };
@@ -464,7 +479,51 @@ void resize_bilinear_kernel(const float* __restrict__ src, float* __restrict__ d
     pointwise_publish<4>(ssum, ssq, active, pl, ppi, cq, C, rs_lds, acc_lds, tot, b, bs, rep, row % rep, tid);
 }
 
-hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, hipStream_t s) {
+// Channel-blocked tensors [B][C/16][H][W][16] (midd_internal.h): grid (rows, B, C/16), thread = (pixel lane 0..63, quad 0..3 of
+// the block) -- a wave reads and writes whole contiguous runs of 16 pixels x 64 bytes.  Same arithmetic and statistics as above.
+__global__ __launch_bounds__(256)
+void resize_bilinear_blocked_kernel(const float* __restrict__ src, float* __restrict__ dst, stat_word* __restrict__ tot, int rep, int bs,
+                                    int H, int W, int C, int OH, int OW, float sy, float sx, int rows) {
+    __shared__ float rs_scratch[2 * 16 * 64];
+    __shared__ stat_word rs_acc[(16 + 2) * STAT_WORDS];
+    const int tid = threadIdx.x;
+    const int pl = tid >> 2, q = tid & 3;
+    const int b = blockIdx.y, row = blockIdx.x, blk = blockIdx.z;
+    const int OHW = OH * OW;
+    const int per = (OHW + rows - 1) / rows;
+    const int p0 = row * per, p1 = min(OHW, p0 + per);
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* base = src + (((size_t)b * (C >> 4) + blk) * (size_t)(H * W)) * 16 + q * 4;
+    float* const obase = dst + (((size_t)b * (C >> 4) + blk) * (size_t)OHW) * 16 + q * 4;
+    for (int p = p0 + pl; p < p1; p += 64) {
+        const int oy = p / OW, ox = p - oy * OW;
+        float fy = sy * ((float)oy + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+        float fx = sx * ((float)ox + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
+        const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * 16);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * 16);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * 16);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * 16);
+        const f32x4 r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        *reinterpret_cast<f32x4*>(obase + (size_t)p * 16) = r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[e] += r[e]; ssq[e] += r[e] * r[e]; }
+    }
+    if (tot == nullptr) return;
+    pointwise_publish<4>(ssum, ssq, true, pl, 64, q, C, rs_scratch, rs_acc, tot, b, bs, rep, row % rep, tid, 256, blk * 16, 16);
+}
+
+hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, int blocked, hipStream_t s) {
+    if (blocked) {
+        if (C % 16) return hipErrorInvalidValue;
+        const int rows_b = pointwise_rows(OH * OW, 64);
+        hipLaunchKernelGGL(resize_bilinear_blocked_kernel, dim3(rows_b, B, C / 16), dim3(256), 0, s,
+                           src, dst, tot, rep, bs, H, W, C, OH, OW, (float)H / (float)OH, (float)W / (float)OW, rows_b);
+        return hipGetLastError();
+    }
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
     const int ppi = 256 / (C / 4);
     const int rows = pointwise_rows(OH * OW, ppi);
@@ -480,7 +539,7 @@ hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, 
 // over taps with (oy+1-ky), (ox+1-kx) even and in range.  Thread = (output pixel, 4 couts).
 __global__ __launch_bounds__(256)
 void conv_transpose_kernel(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias,
-                           float* __restrict__ dst, int B, int H, int W, int Cin, int Cout) {
+                           float* __restrict__ dst, int B, int H, int W, int Cin, int Cout, int blocked) {
     const int OH = 2 * H, OW = 2 * W, CQ = Cout >> 2;
     const long total = (long)B * OH * OW * CQ;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -497,26 +556,26 @@ void conv_transpose_kernel(const float* __restrict__ src, const float* __restric
         for (int kx = 0; kx < 4; ++kx) {
             const int nx = ox + 1 - kx;
             if (nx < 0 || (nx & 1) || (nx >> 1) >= W) continue;
-            const float* ip = src + ((size_t)(b * H + (ny >> 1)) * W + (nx >> 1)) * Cin;
+            const int ipix = (ny >> 1) * W + (nx >> 1);
             const float* wp = w + ((size_t)(ky * 4 + kx) * Cin) * Cout + cq * 4;
             for (int ci = 0; ci < Cin; ++ci)
-                acc += ip[ci] * *reinterpret_cast<const f32x4*>(wp + (size_t)ci * Cout);
+                acc += src[act_index(blocked, b, Cin, H * W, ipix, ci)] * *reinterpret_cast<const f32x4*>(wp + (size_t)ci * Cout);
         }
     }
-    *reinterpret_cast<f32x4*>(dst + (size_t)pix * Cout + cq * 4) = acc;
+    *reinterpret_cast<f32x4*>(dst + act_index(blocked, b, Cout, OH * OW, oy * OW + ox, cq * 4)) = acc;
 }
 
 hipError_t conv_transpose_launch(const float* src, const float* w, const float* bias, float* dst,
-                                 int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+                                 int B, int H, int W, int Cin, int Cout, int blocked, hipStream_t s) {
     if (Cout % 4) return hipErrorInvalidValue;
     const long total = (long)B * 4 * H * W * (Cout / 4);
     hipLaunchKernelGGL(conv_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       src, w, bias, dst, B, H, W, Cin, Cout);
+                       src, w, bias, dst, B, H, W, Cin, Cout, blocked);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------ helpers
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int C) {
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int W, int C, int blocked) {
     const long total = (long)B * H * W * C;
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
@@ -524,12 +583,12 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __rest
     const long pix = gid / C;
     const long hw = pix % ((long)H * W);
     const int b = (int)(pix / ((long)H * W));
-    dst[((size_t)b * C + c) * H * W + hw] = src[gid];
+    dst[((size_t)b * C + c) * H * W + hw] = src[act_index(blocked, b, C, H * W, (int)hw, c)];
 }
 
-hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, hipStream_t s) {
+hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, int blocked, hipStream_t s) {
     const long total = (long)B * H * W * C;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, B, H, W, C);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, B, H, W, C, blocked);
     return hipGetLastError();
 }
 
