@@ -118,7 +118,13 @@ template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, bool RES, 
 // (2 -> 3 workgroups per CU is worth ~25 %: the phases of one workgroup do not overlap themselves)
 // (stride-2 tiles stage a 33x17 halo: their LDS allows one workgroup per CU anyway, so they get the whole register file)
 // (wide chunks: two workgroups per CU by their LDS, so two waves per SIMD's worth of registers)
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && STRIDE == 1) ? (CBT == 2 ? 2 : MIDD_CONV16_WAVES_PER_SIMD) : 1)
+// The 128-pixel tile with the folded res_conv needs ~200 registers: capped at 168 it spilled 51 of them at every tile boundary --
+// 34 MB of scratch writes and as many reads per 256x256 launch (WRITE_SIZE 84 MB for a 50 MB output, tools/traffic_per_op.sh).
+// With two waves per SIMD's worth of registers nothing spills: same-box +4.4 % split, +0.6 % unsplit (round 3).
+#ifndef MIDD_RES_MT2_WAVES
+#define MIDD_RES_MT2_WAVES 2
+#endif
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && STRIDE == 1) ? (CBT == 2 ? 2 : (RES && MT == 2) ? MIDD_RES_MT2_WAVES : MIDD_CONV16_WAVES_PER_SIMD) : 1)
 void conv_mfma_f16x3_kernel(const ConvArgs a) {
     using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN, CBT>;
     constexpr int NW = G::NW, NTHREADS = G::NTHREADS, TH = G::TH, IW = G::IW;

@@ -3,8 +3,8 @@
 // Each binary times the three kernels at B = 4, 256x256 (the sizes of a half-batch program), 20 repetitions.
 #include "../../medical-image-denoising-using-diffusion_amd/csrc/pointwise.hip"
 #include <cstdio>
-#ifndef BLOCKED
-#define BLOCKED 1      // activation layout of the split-fp16 plans (midd_internal.h)
+#ifndef PW_BLOCKED
+#define PW_BLOCKED 1      // activation layout of the split-fp16 plans (midd_internal.h)
 #endif
 #include <vector>
 using namespace midd;
@@ -30,15 +30,15 @@ int main() {
             CK(hipEventRecord(e0)); CK(fn()); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r >= 0) total += ms;
         }
-        printf("PW_ABL=%d blocked=%d %-10s %7.1f us  %5.2f TB/s\n", PW_ABL, BLOCKED, name, total / reps * 1e3, bytes / (total / reps * 1e-3) * 1e-12);
+        printf("PW_ABL=%d blocked=%d %-10s %7.1f us  %5.2f TB/s\n", PW_ABL, PW_BLOCKED, name, total / reps * 1e3, bytes / (total / reps * 1e-3) * 1e-12);
         return 0;
     };
-    if (timeit("in_conv", [&] { return in_conv_launch(x, cond, w, bias, out, tot, 4, 6, B, 1, H, W, C, BLOCKED, 0); }, act * 4.0)) return 1;
+    if (timeit("in_conv", [&] { return in_conv_launch(x, cond, w, bias, out, tot, 4, 6, B, 1, H, W, C, PW_BLOCKED, 0); }, act * 4.0)) return 1;
     OutConvArgs a{};
     a.src = out; a.gn_tot = tot; a.stat_rep = 4; a.gn_bs = 6; a.gn_gamma = gam; a.gn_beta = bet; a.gn_eps = 1e-5f; a.w = w; a.bias = bias;
-    a.blocked = BLOCKED; a.B = B; a.H = H; a.W = W; a.C = C; a.ic = 1; a.eps_out = nullptr; a.x = img; a.noise = nullptr; a.c1 = 1.f; a.c2 = 0.1f; a.c3 = 0.f; a.clamp_eps = 0;
+    a.blocked = PW_BLOCKED; a.B = B; a.H = H; a.W = W; a.C = C; a.ic = 1; a.eps_out = nullptr; a.x = img; a.noise = nullptr; a.c1 = 1.f; a.c2 = 0.1f; a.c3 = 0.f; a.clamp_eps = 0;
     if (timeit("out_conv", [&] { return out_conv_launch(a, 0); }, act * 4.0)) return 1;
-    if (timeit("resize256", [&] { return resize_bilinear_launch(reinterpret_cast<const float*>(lo), out, tot, 4, 6, B, 128, 128, C, 256, 256, BLOCKED, 0); }, act * 5.0)) return 1;
-    if (timeit("resize128", [&] { return resize_bilinear_launch(reinterpret_cast<const float*>(lo), out, tot, 4, 12, B, 64, 64, 96, 128, 128, BLOCKED, 0); }, (double)B * 128 * 128 * 96 * 5.0)) return 1;
+    if (timeit("resize256", [&] { return resize_bilinear_launch(reinterpret_cast<const float*>(lo), out, tot, 4, 6, B, 128, 128, C, 256, 256, PW_BLOCKED, 0); }, act * 5.0)) return 1;
+    if (timeit("resize128", [&] { return resize_bilinear_launch(reinterpret_cast<const float*>(lo), out, tot, 4, 12, B, 64, 64, 96, 128, 128, PW_BLOCKED, 0); }, (double)B * 128 * 128 * 96 * 5.0)) return 1;
     return 0;
 }
