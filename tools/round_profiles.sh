@@ -10,6 +10,7 @@ python tools/per_op_profile.py 4 256 > $OUT/per_op_b4_256.txt 2>&1; head -2 $OUT
 python tools/per_op_profile.py 8 256 > $OUT/per_op_b8_256.txt 2>&1; head -2 $OUT/per_op_b8_256.txt | tail -1
 python tools/per_op_profile.py 4 512 > $OUT/per_op_b4_512.txt 2>&1; head -2 $OUT/per_op_b4_512.txt | tail -1
 bash tools/pmc_passes.sh $OUT/pmc > $OUT/pmc_passes.log 2>&1; echo "pmc_passes rc=$?"
+bash tools/traffic_per_op.sh $TAG 4 > $OUT/traffic_per_op_b4.txt 2>&1
 bash tools/inv_bench.sh > $OUT/batch_invariant_cost.txt 2>&1; cat $OUT/batch_invariant_cost.txt
 ./tools/mb/hbm_rate > $OUT/mb_hbm_rate.txt 2>&1
 ./tools/mb/pw_abl_0 > $OUT/mb_pointwise.txt 2>&1; cat $OUT/mb_pointwise.txt
