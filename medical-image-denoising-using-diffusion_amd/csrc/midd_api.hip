@@ -847,6 +847,10 @@ static int build_program(mi_plan* p, int B, int H, int W, Program* g) {
 // A/B +2.5 % split, while an unsplit run loses 4 % with 640)
 static int get_program(mi_plan* p, int B, int H, int W, Program** out, bool side_by_side = false) {
     if (!p->finalized) return fail(MI_ESTATE, "mi_unet_finalize has not been called (or weights changed since)");
+    // development knob (tools/profile_round.sh): plan a program that runs alone exactly as a side-by-side sub-batch program is
+    // planned, so that counter passes can measure the default run's launches without the other stream's traffic in their windows
+    static const bool plan_as_side = getenv("MIDD_PLAN_AS_SIDE") != nullptr;
+    side_by_side = side_by_side || plan_as_side;
     const uint64_t key = ((uint64_t)(side_by_side ? 1 : 0) << 63) ^ ((uint64_t)B << 40) ^ ((uint64_t)H << 20) ^ (uint64_t)W;
     std::lock_guard<std::mutex> lk(p->mu);
     auto it = p->programs.find(key);

@@ -3,12 +3,13 @@
 // in_channels == 1 in every reference call site) are NCHW.  Two layouts:
 //   fp32-MFMA plans   NHWC            [B][H][W][C]
 //   split-fp16 plans  CHANNEL-BLOCKED [B][C/16][H][W][16]   (round 3)
-// The f16x3 kernels stage a K chunk of 16 channels at a time.  In NHWC a chunk is 64 bytes of every pixel's C*4-byte row: L2
-// fetches whole 128-byte lines, a chunk pass touches 2/3 of the tensor's lines (C = 48), three passes fetch it twice --
-// measured (rocprofv3 FETCH_SIZE calibrated on this very pattern, tools/mb/fetch_calib.hip): 63 MB per launch of the
-// dominant kernel for 33 MB of operands; the L2 of an XCD turns over several times between two chunk passes of a tile.
-// Blocked, a chunk of a halo row is one contiguous run, every fetched line is used whole, and a 16-pixel x 16-cout MFMA
-// tile leaves as ONE contiguous KiB instead of sixteen 64-byte pieces.
+// The f16x3 kernels stage a K chunk of 16 channels at a time.  In NHWC that is 64 bytes of every pixel's C*4-byte row while L2
+// fetches whole 128-byte lines (a chunk pass alone moves twice its bytes: rocprofv3 FETCH_SIZE calibrated on this very
+// pattern, tools/mb/fetch_calib.hip), the MFMA tiles of the epilogue leave as 64-byte pieces C*4 bytes apart, and so do the
+// residual rows.  Blocked, the chunk of a halo row is one contiguous run, a 16-pixel x 16-cout MFMA tile leaves as ONE contiguous
+// KiB, residual rows and the pointwise kernels move whole runs.  Per launch at batch 4, 256x256 (tools/traffic_per_op.sh, L2-side
+// bytes): conv2's fetch 128 -> 115 MB (its residual rows), out_conv 100 -> 64 MB for a 50 MB tensor; the 3x3 kernel's own
+// chunk reads were already close to halo-only (66.5 -> 64.3 MB: the L2 kept the other half of the lines for the next pass).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
