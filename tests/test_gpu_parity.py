@@ -262,6 +262,10 @@ CONFIG_SWEEP = [
     (dict(model_channels=48, channel_mult=(1, 2, 4), num_res_blocks=1, attention_resolutions=(2,), time_emb_dim=96), "cddpm", 2, 20, 12),
     (dict(model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1,), time_emb_dim=32), "cddpm", 1, 6, 10),
     (dict(model_channels=16, channel_mult=(1, 2, 4, 8), num_res_blocks=1, attention_resolutions=(3,), time_emb_dim=32), "cddpm", 2, 16, 16),
+    # more than one image channel (the reference's constructor argument; its call sites use 1): the general in_conv kernel and
+    # the out_conv instance whose output count is a run-time value
+    (dict(in_channels=2, model_channels=32, channel_mult=(1, 2), num_res_blocks=2, attention_resolutions=(1,), time_emb_dim=32), "ddim", 2, 24, 16),
+    (dict(in_channels=3, model_channels=32, channel_mult=(1, 2), num_res_blocks=1, attention_resolutions=(1,), time_emb_dim=32), "cddpm", 1, 16, 16),
 ]
 
 
@@ -275,11 +279,12 @@ def test_other_topologies_forward_vs_oracle(case, compute):
     sd = make_state_dict(cfg, seed=100 + case)
     m = _model(kw, sd, variant=variant, compute=compute)
     rng = np.random.default_rng(case)
-    x = torch.from_numpy(rng.random((B, 1, H, W), dtype=np.float32))
-    cond = torch.from_numpy(synthetic_xray(B, H, W, seed=case))
+    ic = kw.get("in_channels", 1)
+    x = torch.from_numpy(rng.random((B, ic, H, W), dtype=np.float32))
+    cond = torch.from_numpy(np.concatenate([synthetic_xray(B, H, W, seed=case + 31 * c) for c in range(ic)], axis=1))
     t = torch.from_numpy(rng.integers(0, 50, B)).to(torch.int64)
     ref = orc.unet_forward(orc.to_torch(sd), topology(cfg), x, cond, t).numpy()
-    assert ref.shape == (B, 1, H, W)
+    assert ref.shape == (B, ic, H, W)
     got = m(x.cuda(), cond.cuda(), t.cuda()).cpu().numpy()
     d = _maxdiff(got, ref)
     print(f"topology {case} {variant} {compute}: max|eps - oracle| = {d:.3e} (|eps| up to {np.abs(ref).max():.2f})")
