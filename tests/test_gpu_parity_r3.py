@@ -237,3 +237,24 @@ def test_attention_operand_beyond_fp16_is_an_error():
     with pytest.raises(native.MiddError) as ei:
         m(x, c, torch.tensor([11, 45]))
     assert "split-fp16 range" in str(ei.value)
+
+
+# ------------------------------------------------------------------------------ one program on one stream (MI_NO_SPLIT)
+def test_no_split_run_matches_fixture_and_default(full_model):
+    """mi_denoise(flags | MI_NO_SPLIT) runs the batch as ONE program on the caller's stream -- the mode bench.py's
+    `roofline.alone` leg measures, and at batch 8 the only place where the wide-chunk 3x3 instances (conv16_pick_tile:
+    programs that run alone) see 64x64 and 32x32 maps of a full batch.  Same image as the default two-stream run to
+    rounding (the per-program batch changes tiles and partial-sum grouping), both within the gate of the reference fixture."""
+    cfg, sd, model = full_model
+    g = np.load(os.path.join(G, "full_ddim_256.npz"))
+    x = synthetic_xray(8, 256, 256, seed=9400)
+    x[3] = synthetic_xray(1, 256, 256, seed=1234)[0]
+    noisy = torch.from_numpy(x).cuda()
+    den = DiffusionDenoiser(model, noise_steps=50)
+    steps = timestep_list(50, 50)
+    alone = model.run_sampler(noisy, steps, den.beta, den.alpha, den.alpha_hat, clamp_eps=True, no_split=True)
+    both = model.run_sampler(noisy, steps, den.beta, den.alpha, den.alpha_hat, clamp_eps=True)
+    d_fix, d_modes = _maxdiff(alone[3], g["den_out"][0]), _maxdiff(alone, both)
+    print(f"MI_NO_SPLIT ({model.compute}): max|d| vs fixture {d_fix:.2e}, vs the two-stream run {d_modes:.2e}")
+    assert d_fix < TOL_FINAL and d_modes < 1e-4
+    assert torch.isfinite(alone).all() and float(alone.min()) >= 0.0 and float(alone.max()) <= 1.0
