@@ -258,3 +258,38 @@ def test_no_split_run_matches_fixture_and_default(full_model):
     print(f"MI_NO_SPLIT ({model.compute}): max|d| vs fixture {d_fix:.2e}, vs the two-stream run {d_modes:.2e}")
     assert d_fix < TOL_FINAL and d_modes < 1e-4
     assert torch.isfinite(alone).all() and float(alone.min()) >= 0.0 and float(alone.max()) <= 1.0
+
+
+# ------------------------------------------------------------------------------ seeded random shapes
+RANDOM_CASES = 12
+
+
+@pytest.mark.parametrize("compute", COMPUTE_MODES)
+def test_seeded_random_shapes_vs_oracle(compute):
+    """Planner, tile picker, persistent-workgroup walk, key split, ragged tiles and the channel-blocked layout on shapes nobody
+    chose by hand: batch 1..9, H and W any multiples of the network's total stride in 16..104, the reduced reference-valid
+    topology (32/64 channels, attention at the 1/2-resolution level: N up to 2704 keys) -- forward AND a 2-iteration sampler
+    (odd batches and B < 4 run as one program, even ones >= 4 as two half-batch programs) against the oracle.  Seeds fixed:
+    the same 12 cases every run."""
+    rng = np.random.default_rng(20260303)
+    cfg = UNetConfig(**RANGE_KW)
+    sd = make_state_dict(cfg, seed=77)
+    model = _model(RANGE_KW, sd, compute=compute)
+    sdt, topo = orc.to_torch(sd), topology(cfg)
+    den = DiffusionDenoiser(model, noise_steps=50)
+    worst = 0.0
+    for case in range(RANDOM_CASES):
+        B = int(rng.integers(1, 10))
+        H, W = (int(rng.integers(2, 14)) * 8 for _ in range(2))
+        x = torch.from_numpy(rng.random((B, 1, H, W), dtype=np.float32))
+        c = torch.from_numpy(synthetic_xray(B, H, W, seed=500 + case))
+        t = torch.from_numpy(rng.integers(0, 50, B)).to(torch.int64)
+        with torch.no_grad():
+            want = orc.unet_forward(sdt, topo, x, c, t)
+            want_den = orc.denoise(sdt, topo, c, noise_steps=50, inference_steps=2)
+        got = model(x.cuda(), c.cuda(), t.cuda())
+        out = den.denoise(c.cuda(), inference_steps=2)
+        d, dd = _maxdiff(got, want), _maxdiff(out, want_den)
+        worst = max(worst, d, dd)
+        assert d < TOL_EPS * max(1.0, float(want.abs().max())) and dd < TOL_FINAL, f"case {case}: B={B} {H}x{W}: forward {d:.2e}, sampler {dd:.2e}"
+    print(f"seeded random shapes ({compute}): worst max|d| {worst:.2e} over {RANDOM_CASES} cases")
