@@ -83,18 +83,21 @@ def test_non_power_of_two_sizes_vs_oracle(shape, compute):
     x8 = torch.from_numpy(synthetic_xray(8, H, W, seed=31, kind="uniform"))
     c8 = torch.from_numpy(synthetic_xray(8, H, W, seed=32))
     t8 = torch.tensor([49, 3, 17, 0, 25, 40, 9, 33])
+    rows = [0, 2, 5]                       # the oracle is per-sample: three rows of the batch of 8 on the CPU (test time)
     with torch.no_grad():
-        want8 = orc.unet_forward(sdt, topo, x8, c8, t8)
+        want = orc.unet_forward(sdt, topo, x8[rows], c8[rows], t8[rows])
     got8 = model(x8.cuda(), c8.cuda(), t8.cuda())
     got1 = model(x8[2:3].cuda(), c8[2:3].cuda(), t8[2:3].cuda())
-    d8, d1 = _maxdiff(got8, want8), _maxdiff(got1, want8[2:3])
+    assert torch.isfinite(got8).all()
+    d8, d1 = _maxdiff(got8[rows], want), _maxdiff(got1, want[1:2])
     print(f"{H}x{W} {compute}: forward max|d| B=8 {d8:.2e}, B=1 {d1:.2e}")
     assert d8 < TOL_EPS and d1 < TOL_EPS
     den = DiffusionDenoiser(model, noise_steps=50)
     out = den.denoise(c8.cuda(), inference_steps=3)                      # split run: two programs of 4
+    srows = [1, 6]                         # one row of either half-batch
     with torch.no_grad():
-        want = orc.denoise(sdt, topo, c8, noise_steps=50, inference_steps=3)
-    assert _maxdiff(out, want) < TOL_FINAL
+        want_den = orc.denoise(sdt, topo, c8[srows], noise_steps=50, inference_steps=3)
+    assert torch.isfinite(out).all() and _maxdiff(out[srows], want_den) < TOL_FINAL
 
 
 # ------------------------------------------------------------------------------ numerical range, lower end
