@@ -6,7 +6,8 @@
 // chunk barriers, weight ring) is pure latency here: with one K-step per chunk it serialises a DMA round trip
 // per 32 channels.  This kernel instead
 //   * loads each lane's B operand straight from global memory: lane (pixel p16, k-quarter kq) of a 16x16x32
-//     MFMA needs channels kq*8 .. kq*8+7 of its pixel = 32 contiguous bytes in NHWC; GroupNorm-apply / SiLU /
+//     MFMA needs channels kq*8 .. kq*8+7 of its pixel = 32 contiguous bytes inside one 16-channel block of the channel-blocked
+//     layout (midd_internal.h; 16 pixel lanes x two k-quarters read one contiguous KiB); GroupNorm-apply / SiLU /
 //     2^s prescale / hi-lo split happen in registers (each element once per workgroup, as before);
 //   * keeps ALL weights of the workgroup's 16*NT output channels in LDS (Cin * NT * 64 B: 36 KB at Cin = 192),
 //     fetched once by LDS-DMA and reused for every pixel tile the persistent workgroup walks;

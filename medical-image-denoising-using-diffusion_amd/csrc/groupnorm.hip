@@ -1,4 +1,4 @@
-// GroupNorm(8, C) support kernels for NHWC fp32 activations.
+// GroupNorm(8, C) support kernels for fp32 activations (NHWC or channel-blocked, midd_internal.h: act_index).
 //
 // nn.GroupNorm(8, C) on the reference's hot path (/root/reference/Backend/DDIM/DDIMModel.py:116,121,139,214; eps =
 // 1e-5, affine) never runs as a kernel of its own here (stats_common.h): the PRODUCER of a tensor leaves per-channel

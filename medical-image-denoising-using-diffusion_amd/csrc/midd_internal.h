@@ -48,8 +48,8 @@ struct ConvArgs {          // (activation pointers: NHWC for the fp32-MFMA kerne
     const float* temb;      // time table [rows][temb_stride], already offset to this block's column
     int temb_stride;
     const int* trow;        // [B] table row per sample
-    const float* resid;     // NHWC [B][OH][OW][Cout] added in the epilogue, or null
-    float* out;             // NHWC [B][OH][OW][Cout]
+    const float* resid;     // [B][OH][OW][Cout] (layout as above) added in the epilogue, or null
+    float* out;             // [B][OH][OW][Cout] (layout as above)
     float out_scale;        // f16x3 only: 2^-(k+s) undoing the operand prescales (1 for fp32)
     // optional fused GroupNorm statistics of the OUTPUT: every workgroup adds the per-channel sum / sum of squares of
     // the pixels it produced to the totals [B][Cout/bs][rep][2][3] (exact integer atomics, stats_common.h); zeroed per forward
@@ -123,7 +123,7 @@ __host__ __device__ inline int conv16_num_steps(int Cin, int taps, int cb = 0) {
 
 // ---------------------------------------------------------------- GroupNorm statistics (stats_common.h)
 constexpr int GN_GROUPS_ = 8;                  // nn.GroupNorm(8, C) everywhere in the reference (DDIMModel.py:116,121,139,214)
-// per-channel totals of an NHWC tensor no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
+// per-channel totals of an activation tensor (either layout: `blocked`) no MFMA conv produced (in_conv output, bilinear 2x outputs): `rows` blocks per
 // sample each add their partial sums to tot [B][C/bs][rep][2][3]
 hipError_t chan_total_launch(const float* src, stat_word* tot, int rep, int bs, int B, int HW, int C, int rows, int blocked, hipStream_t s);
 int chan_partial_rows(int HW, int C);
@@ -152,7 +152,7 @@ void attention16_split(int N, int heads, int split_B, int* ksplit, int* tiles_pe
 bool attention_supported(int head_dim);
 
 // ---------------------------------------------------------------- small direct kernels
-// in_conv: Conv3x3 on cat[x, cond] (NCHW [B,ic,H,W] each) -> NHWC [B][H][W][Cout]
+// in_conv: Conv3x3 on cat[x, cond] (NCHW [B,ic,H,W] each) -> [B][H][W][Cout] activations (NHWC, or channel-blocked when `blocked`)
 // tot != nullptr: also leaves the GroupNorm totals of the output [B][Cout/bs][rep][2][3] (stats_common.h)
 hipError_t in_conv_launch(const float* x, const float* cond, const float* w /*[9][2ic][Cout]*/, const float* bias,
                           float* out, stat_word* tot, int rep, int bs, int B, int ic, int H, int W, int Cout, int blocked, hipStream_t s);
@@ -173,12 +173,12 @@ struct OutConvArgs {
 };
 hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s);
 
-// bilinear resize NHWC (align_corners=False), any size ratio
+// bilinear resize of an activation tensor, either layout (align_corners=False), any size ratio
 hipError_t resize_bilinear_launch(const float* src, float* dst, stat_word* tot, int rep, int bs, int B, int H, int W, int C, int OH, int OW, int blocked, hipStream_t s);
 // ConvTranspose2d(C,C,4,stride=2,padding=1) direct (only used by topologies where it cannot be folded)
 hipError_t conv_transpose_launch(const float* src, const float* w /*[4][4][Cin][Cout]*/, const float* bias, float* dst,
                                  int B, int H, int W, int Cin, int Cout, int blocked, hipStream_t s);
-// NHWC -> NCHW copy (debug fetch)
+// activation tensor (either layout) -> NCHW copy (debug fetch)
 hipError_t nhwc_to_nchw_launch(const float* src, float* dst, int B, int H, int W, int C, int blocked, hipStream_t s);
 hipError_t fill_i32_launch(int* dst, const int* host_vals, int n, hipStream_t s);
 

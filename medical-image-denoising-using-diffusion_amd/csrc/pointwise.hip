@@ -132,8 +132,10 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
 // is bound by its instruction stream and its latencies (72 per-lane LDS weight reads and a branch per tap for 288
 // multiply-adds; three threads load each pixel's taps; 1.5 waves per SIMD), and its stores, 16 bytes per lane 64 bytes
 // apart, reach 2.4 TB/s where contiguous ones reach 4 (tools/mb/hbm_rate.hip).  Here every WAVE works on its own:
-//   lane = pixel, all Cout outputs of it: the weights are uniform (scalar loads, SGPR operands: no LDS, no weight
-//   registers), the 18 taps are loaded once per pixel, branch-free from clamped addresses, coalesced, one pass ahead;
+//   lane = pixel, all Cout outputs of it: the weights are uniform -- broadcast reads from LDS, half of the couts at a time with
+//   the next tap's quads requested before this tap's multiply-adds (IC1_WLDS; as scalar loads with SGPR operands they
+//   cost 620 cycles per tap: SMEM returns out of order, every use waits for all of it) -- the 18 taps are loaded once per
+//   pixel, branch-free from clamped addresses, coalesced, one pass ahead;
 //   the wave's [64 pixels][Cout] tile is turned through its OWN LDS patch (no workgroup barrier in the loop) and
 //   leaves as whole contiguous rows, every lane 16 bytes next to its neighbour's;
 //   the statistics are summed on the values in store order: a lane meets NQ / gcd(64, NQ) different channel quads.
@@ -154,6 +156,14 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const tile = ic1_lds + wave * (64 * PS);
+#ifndef IC1_WLDS
+#define IC1_WLDS 1
+#endif
+#if IC1_WLDS
+    float* const wlds = ic1_lds + 4 * 64 * PS + ((COUT + 2) * STAT_WORDS * 2 + 4);      // behind the tiles and the publish accumulators: [18][COUT] weights, [COUT] bias
+    for (int i = tid; i < 19 * COUT; i += 256) wlds[i] = (i < 18 * COUT) ? w[i] : bias[i - 18 * COUT];
+    __syncthreads();
+#endif
     const int b = blockIdx.y, HW = H * W;
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
     const float* const xp = x + (size_t)b * HW;
@@ -191,6 +201,36 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
 #pragma unroll
         for (int i = 0; i < 18; ++i) v[i] = vn[i];
         if (base + 256 < p1) load_taps(base + 256, vn);           // next pass's taps fly under this pass's arithmetic
+#if IC1_WLDS
+        // Weights from LDS (uniform address: a broadcast read), half of the couts at a time so that the NEXT tap's quads fit in
+        // registers beside the accumulators: LDS reads return in order, the compiler's counted waits keep several in flight.
+        // (Scalar loads return out of order: every use waits for ALL of them, lgkmcnt(0) -- one tap in flight, ~620 cycles per tap.)
+        int wofs = 0;                                             // opaque per pass: otherwise the weights are hoisted out of the pass loop
+        asm volatile("" : "+v"(wofs));
+        const float* const wl = wlds + wofs;
+        constexpr int NQH = NQ / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 acc[NQH], wv[2][NQH];
+            auto wload = [&](int i, f32x4 (&d)[NQH]) {
+#pragma unroll
+                for (int q = 0; q < NQH; ++q) d[q] = *reinterpret_cast<const f32x4*>(wl + ((i % 9) * 2 + i / 9) * COUT + (h * NQH + q) * 4);
+            };
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) acc[q] = *reinterpret_cast<const f32x4*>(wl + 18 * COUT + (h * NQH + q) * 4);
+            wload(0, wv[0]);
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                if (i + 1 < 18) wload(i + 1, wv[(i + 1) & 1]);
+#pragma unroll
+                for (int q = 0; q < NQH; ++q) acc[q] += v[i] * wv[i & 1][q];
+#pragma unroll
+                for (int q = 0; q < NQH; ++q) asm volatile("" : "+v"(acc[q]));      // pinned: not sunk to the tile stores with all weights live
+            }
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) *reinterpret_cast<f32x4*>(&tile[lane * PS + (h * NQH + q) * 4]) = acc[q];
+        }
+#else
         int wofs = 0;                                             // opaque per pass: otherwise all 18 * COUT weights are hoisted out of the
         asm volatile("" : "+s"(wofs));                            // loop as loop invariants -- 864 SGPRs, spilled to VGPR lanes
         const float* const wp = w + wofs;
@@ -209,6 +249,7 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
         }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(&tile[lane * PS + q * 4]) = acc[q];
+#endif
         // the wave's own patch: its LDS operations execute in order, no barrier
         const int npx = min(64, p1 - base);
 #pragma unroll
@@ -276,7 +317,7 @@ static hipError_t in_conv1_launch(const float* x, const float* cond, const float
     constexpr int G64 = (NQ % 16 == 0) ? 16 : (NQ % 8 == 0) ? 8 : (NQ % 4 == 0) ? 4 : (NQ % 2 == 0) ? 2 : 1;
     constexpr int SLOTS = BLOCKED ? 64 : 4 * (NQ / G64) * ((64 + NQ - 1) / NQ);
     static_assert(2 * COUT * SLOTS <= 4 * 64 * PS, "the statistics scratch aliases the tiles");
-    const size_t lds = (size_t)4 * 64 * PS * sizeof(float) + (size_t)(COUT + 2) * STAT_WORDS * sizeof(stat_word) + 16;
+    const size_t lds = (size_t)4 * 64 * PS * sizeof(float) + (size_t)(COUT + 2) * STAT_WORDS * sizeof(stat_word) + 16 + (size_t)19 * COUT * sizeof(float);
     hipLaunchKernelGGL((in_conv1_kernel<COUT, BLOCKED>), dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, H, W, per);
     return hipGetLastError();
 }
@@ -324,8 +365,6 @@ void out_conv_kernel(const OutConvArgs a, const float* __restrict__ wglob /* == 
     const int oy0 = (trem / tiles_x) * OC_T, ox0 = (trem % tiles_x) * OC_T;
     const int C = a.C;
     if constexpr (IC == 0) for (int i = tid; i < ic * 9 * C; i += 256) wl[i] = a.w[i];     // (IC > 0 reads the weights through scalar loads)
-    // (second source: C1 = 0, never read; a literal nullptr there crashes hipcc 7.2's inliner)
-    gn_prologue_lds(a.gn_tot, C, a.gn_bs, a.gn_tot, 0, 1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, 1.0 / ((double)a.H * a.W * (C / GN_GROUPS_C)), b, 1.0f, gnp, tid, 256);
 
     float acc[4] = {0.f, 0.f, 0.f, 0.f};          // ic <= 4 output channels
     // Staging, round 3: a thread's slots (halo pixel, channel quad) are the same for every 16-channel chunk, so their
@@ -359,7 +398,9 @@ void out_conv_kernel(const OutConvArgs a, const float* __restrict__ wglob /* == 
 #endif
         }
     };
-    prefetch(0);
+    prefetch(0);                                  // the first chunk's quads fly while the GroupNorm scale / shift are derived
+    // (second source: C1 = 0, never read; a literal nullptr there crashes hipcc 7.2's inliner)
+    gn_prologue_lds(a.gn_tot, C, a.gn_bs, a.gn_tot, 0, 1, a.stat_rep, a.gn_gamma, a.gn_beta, a.gn_eps, 1.0 / ((double)a.H * a.W * (C / GN_GROUPS_C)), b, 1.0f, gnp, tid, 256);
     for (int c0 = 0; c0 < C; c0 += 16) {
         __syncthreads();                          // the previous chunk's taps are done with the tile
 #pragma unroll
@@ -436,7 +477,7 @@ hipError_t out_conv_launch(const OutConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------ bilinear resize (NHWC)
+// ------------------------------------------------------------------------------ bilinear resize (NHWC; the channel-blocked variant follows)
 // Same index/weight arithmetic as ATen's upsample_bilinear2d with align_corners=False:
 //   src = max(0, scale*(dst+0.5)-0.5), scale = in/out;  i0 = floor(src), i1 = i0 + (i0 < in-1), l1 = src - i0.
 // grid (rows, B); also leaves the GroupNorm totals of its output (pointwise_publish)
