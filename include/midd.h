@@ -147,6 +147,13 @@ int mi_debug_fetch(mi_plan* plan, const char* module_name, int B, int H, int W,
  * Every split owns at least one tile for every N >= 1 (tests sweep it). */
 int mi_debug_attention_split(int N, int B, int* ksplit, int* tiles_per_split);
 
+/* Debug/test hook, host only (no GPU call, no finalize needed): the execution program the planner builds for (B, H, W) as
+ * text, one line per kernel launch: kernel instantiation, tile, grid, persistent workgroups per sample, weight-ring depth and
+ * DMA pieces per wave, folded res_conv steps, attention key split, LDS bytes.  side_by_side != 0: the sub-batch program the
+ * two-stream mi_denoise runs (the reference has no counterpart: its graph is fixed, DDIMModel.py:219-248).  Writes at most
+ * cap - 1 characters + NUL to buf (may be NULL) and returns the full length, or a negative MI_E* code. */
+int mi_debug_plan_dump(mi_plan* plan, int B, int H, int W, int side_by_side, char* buf, size_t cap);
+
 /* First 16 hex digits of the sha256 over the kernel sources (csrc/ *.h, *.hip) this library was BUILT from, embedded at
  * build time: what bench.py / tools/pmc_traffic.py compare profiles against (not the working tree). */
 const char* mi_source_hash(void);

@@ -397,6 +397,18 @@ bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t) {
     return true;
 }
 
+bool conv1x1_launch_info(int Cin, int Cout, int B, int OH, int OW, const ConvTile& t, int persist_wgs, int att_mode, ConvLaunchInfo* o) {
+    const int bm = 4 * t.mt * 16, HW = OH * OW;
+    o->tiles_x = (HW + bm - 1) / bm; o->tiles_y = 1;
+    o->grid_y = Cout / (t.nt * 16);
+    o->wgs_per_img = conv16_wgs_per_img(o->tiles_x, B, o->grid_y, persist_wgs);
+    o->grid_x = B * o->wgs_per_img;
+    o->ring = 0; o->ppw = 0; o->apw = 0;
+    const int w = ((Cin + 31) / 32) * t.nt * 2048;
+    o->lds_bytes = (w < 4096 ? 4096 : w) + (4 * 2 * t.nt * 16 + t.nt * 16) * 4 + 2 * Cin * 4 + 64 + (att_mode == ATT_PART_IN ? C1_MAX_SPLIT * 2 * bm * 4 : 0);
+    return true;
+}
+
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (a.C0 % 16 || a.C1 % 16) return hipErrorInvalidValue;  // whole 16-channel blocks per source (channel-blocked activations)
     if (a.att_mode != ATT_NONE) {

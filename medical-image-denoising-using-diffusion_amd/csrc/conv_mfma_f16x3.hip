@@ -906,6 +906,34 @@ bool conv16_pick_tile(int Cin, int Cout, int B, int OH, int OW, int ks, int stri
     return true;
 }
 
+template <int KS, int STRIDE, int TW, int MT, int NT, int WM, int WN, int CBT = 0>
+static bool info16(int Cin, int Cout, int B, int OH, int OW, int persist_wgs, ConvLaunchInfo* o) {
+    using G = Conv16Geom<KS, STRIDE, TW, MT, NT, WM, WN, CBT>;
+    o->tiles_x = (OW + TW - 1) / TW; o->tiles_y = (OH + G::TH - 1) / G::TH;
+    o->grid_y = Cout / (WN * NT * 16);
+    o->wgs_per_img = conv16_wgs_per_img(o->tiles_x * o->tiles_y, B, o->grid_y, persist_wgs);
+    o->grid_x = B * o->wgs_per_img;
+    o->ring = G::RING; o->ppw = G::PPW; o->apw = G::APW; o->lds_bytes = G::lds_bytes(Cin);
+    return true;
+}
+bool conv16_launch_info(int Cin, int Cout, int B, int OH, int OW, const ConvTile& t, int persist_wgs, ConvLaunchInfo* out) {
+    if (t.ks == 1 && t.tw == 0) return conv1x1_launch_info(Cin, Cout, B, OH, OW, t, persist_wgs, ATT_NONE, out);
+    if (t.cb == 2) {
+        if (t.mt == 2) return info16<3, 1, 16, 2, 3, 4, 1, 2>(Cin, Cout, B, OH, OW, persist_wgs, out);
+        if (t.mt == 1) return info16<3, 1, 16, 1, 3, 4, 1, 2>(Cin, Cout, B, OH, OW, persist_wgs, out);
+        return false;
+    }
+#define X(tw_, mt_, nt_, wm_, wn_)                                                            \
+    if (t.tw == tw_ && t.mt == mt_ && t.nt == nt_ && t.wm == wm_ && t.wn == wn_) {           \
+        if (t.ks == 3 && t.stride == 1) return info16<3, 1, tw_, mt_, nt_, wm_, wn_>(Cin, Cout, B, OH, OW, persist_wgs, out); \
+        if (t.ks == 3 && t.stride == 2) return info16<3, 2, tw_, mt_, nt_, wm_, wn_>(Cin, Cout, B, OH, OW, persist_wgs, out); \
+        if (t.ks == 1 && t.stride == 1) return info16<1, 1, tw_, mt_, nt_, wm_, wn_>(Cin, Cout, B, OH, OW, persist_wgs, out); \
+    }
+    MIDD_CONV16_TILES(X)
+#undef X
+    return false;
+}
+
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s) {
     if (t.ks == 1 && t.tw == 0) return conv1x1_launch(a, t, s);
     if (t.cb == 2) {          // wide chunks: the two 4x1-wave tiles the picker marks (conv16_pick_tile)

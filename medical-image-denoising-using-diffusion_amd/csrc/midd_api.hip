@@ -953,6 +953,48 @@ static void op_work(mi_plan* p, Program* g, const Op& o, std::string* name, doub
     }
 }
 
+// Debug/test hook, host only: the execution program the planner builds for (B, H, W) -- one line per launch with its tile,
+// grid, persistent workgroups, ring depth / DMA pieces, res steps, key split and LDS bytes.  side_by_side: as a sub-batch
+// program of the two-stream run is planned.  Needs no finalize (weight offsets print as 0).  Returns the text length.
+static int dump_program(mi_plan* p, int B, int H, int W, bool side_by_side, std::string* out) {
+    Program g;
+    g.persist_wgs = side_by_side ? 640 : 0;
+    if (p->batch_invariant) g.persist_wgs = 640 / INVARIANT_B * B;
+    g.wide_chunks = !side_by_side && !p->batch_invariant;
+    int rc = build_program(p, B, H, W, &g);
+    if (rc) return rc;
+    char line[512];
+    snprintf(line, sizeof line, "program B=%d %dx%d side=%d bytes=%zu stats_off=%zu stats_bytes=%zu stat_rep=%d persist_wgs=%d wide=%d ops=%zu\n",
+             B, H, W, (int)side_by_side, g.bytes, g.stats_off, g.stats_bytes, g.stat_rep, g.persist_wgs, (int)g.wide_chunks, g.ops.size());
+    *out += line;
+    static const char* kinds[] = {"in_conv", "conv", "attn", "resize", "convT", "out", "chan_tot"};
+    int idx = 0;
+    for (const Op& o : g.ops) {
+        std::string name; double fl, by;
+        op_work(p, &g, o, &name, &fl, &by);
+        int n = snprintf(line, sizeof line, "op%03d %-8s %dx%d c%d+%d->%d k%d s%d pro%d res_steps%d att%d ksplit%d tps%d bs(in %d,%d out %d) | %s",
+                         idx++, kinds[o.kind], o.dst.H ? o.dst.H : H, o.dst.W ? o.dst.W : W, o.s0.C, o.has_s1 ? o.s1.C : 0, o.dst.C, o.ks, o.stride,
+                         o.prologue, o.res_steps, o.att_mode, o.att_ksplit, o.att_tps, o.s0.stat_bs, o.has_s1 ? o.s1.stat_bs : 0, o.dst.stat_bs, name.c_str());
+        if (o.kind == OP_CONV && p->cfg.compute_mode == MI_COMPUTE_F16X3) {
+            ConvLaunchInfo li{};
+            if (conv16_launch_info(o.s0.C + (o.has_s1 ? o.s1.C : 0), o.dst.C, B, o.dst.H, o.dst.W, o.tile, g.persist_wgs, &li))
+                n += snprintf(line + n, sizeof line - n, " | grid %dx%d wgs/img %d tiles %dx%d ring %d ppw %d apw %d lds %d", li.grid_x, li.grid_y, li.wgs_per_img,
+                              li.tiles_x, li.tiles_y, li.ring, li.ppw, li.apw, li.lds_bytes);
+        }
+        snprintf(line + n, sizeof line - n, "\n");
+        *out += line;
+    }
+    return MI_OK;
+}
+extern "C" int mi_debug_plan_dump(mi_plan* plan, int B, int H, int W, int side_by_side, char* buf, size_t cap) {
+    if (!plan) return fail(MI_EINVAL, "null plan");
+    std::string text;
+    int rc = dump_program(plan, B, H, W, side_by_side != 0, &text);
+    if (rc) return rc;
+    if (buf && cap) { snprintf(buf, cap, "%s", text.c_str()); }
+    return (int)text.size();
+}
+
 // status: the call's status word (first word of the CALLER's workspace, whichever sub-batch program runs)
 static int run_program(mi_plan* p, Program* g, const StepIO& io, char* ws, int* status, hipStream_t s,
                        hipEvent_t mid_event = nullptr, int mid_div = 2) {

@@ -103,6 +103,10 @@ int conv16_wgs_per_img(int tiles, int B, int ny, int target = 0);   // target 0:
 bool conv1x1_pick_tile(int Cin, int Cout, int B, int OH, int OW, ConvTile* t);   // ConvTile::tw == 0 marks it
 hipError_t conv1x1_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);      // persistent workgroups per sample (f16x3 kernels)
 hipError_t conv16_launch(const ConvArgs& a, const ConvTile& t, hipStream_t s);
+// launch geometry of an f16x3 convolution, host only (mi_debug_plan_dump; tests that pin which instantiations a shape reaches)
+struct ConvLaunchInfo { int grid_x, grid_y, wgs_per_img, tiles_x, tiles_y, ring, ppw, apw, lds_bytes; };
+bool conv16_launch_info(int Cin, int Cout, int B, int OH, int OW, const ConvTile& t, int persist_wgs, ConvLaunchInfo* out);
+bool conv1x1_launch_info(int Cin, int Cout, int B, int OH, int OW, const ConvTile& t, int persist_wgs, int att_mode, ConvLaunchInfo* out);
 // 16-channel blocks staged per K chunk of the f16x3 kernel (shared with the host packer).
 //   3x3: 1 -> 16 channels per chunk, two taps per MFMA step (10 % padded MFMA slots, but half the
 //             activation LDS of a 32-channel chunk, i.e. three resident workgroups per CU)

@@ -133,7 +133,7 @@ void in_conv_kernel(const float* __restrict__ x, const float* __restrict__ cond,
 // multiply-adds; three threads load each pixel's taps; 1.5 waves per SIMD), and its stores, 16 bytes per lane 64 bytes
 // apart, reach 2.4 TB/s where contiguous ones reach 4 (tools/mb/hbm_rate.hip).  Here every WAVE works on its own:
 //   lane = pixel, all Cout outputs of it: the weights are uniform -- broadcast reads from LDS, half of the couts at a time with
-//   the next tap's quads requested before this tap's multiply-adds (IC1_WLDS; as scalar loads with SGPR operands they
+//   the next tap's quads requested before this tap's multiply-adds (as scalar loads with SGPR operands they
 //   cost 620 cycles per tap: SMEM returns out of order, every use waits for all of it) -- the 18 taps are loaded once per
 //   pixel, branch-free from clamped addresses, coalesced, one pass ahead;
 //   the wave's [64 pixels][Cout] tile is turned through its OWN LDS patch (no workgroup barrier in the loop) and
@@ -156,14 +156,9 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* const tile = ic1_lds + wave * (64 * PS);
-#ifndef IC1_WLDS
-#define IC1_WLDS 1
-#endif
-#if IC1_WLDS
     float* const wlds = ic1_lds + 4 * 64 * PS + ((COUT + 2) * STAT_WORDS * 2 + 4);      // behind the tiles and the publish accumulators: [18][COUT] weights, [COUT] bias
     for (int i = tid; i < 19 * COUT; i += 256) wlds[i] = (i < 18 * COUT) ? w[i] : bias[i - 18 * COUT];
     __syncthreads();
-#endif
     const int b = blockIdx.y, HW = H * W;
     const int p0 = blockIdx.x * per, p1 = min(HW, p0 + per);
     const float* const xp = x + (size_t)b * HW;
@@ -201,7 +196,6 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
 #pragma unroll
         for (int i = 0; i < 18; ++i) v[i] = vn[i];
         if (base + 256 < p1) load_taps(base + 256, vn);           // next pass's taps fly under this pass's arithmetic
-#if IC1_WLDS
         // Weights from LDS (uniform address: a broadcast read), half of the couts at a time so that the NEXT tap's quads fit in
         // registers beside the accumulators: LDS reads return in order, the compiler's counted waits keep several in flight.
         // (Scalar loads return out of order: every use waits for ALL of them, lgkmcnt(0) -- one tap in flight, ~620 cycles per tap.)
@@ -222,34 +216,31 @@ void in_conv1_kernel(const float* __restrict__ x, const float* __restrict__ cond
 #pragma unroll
             for (int i = 0; i < 18; ++i) {
                 if (i + 1 < 18) wload(i + 1, wv[(i + 1) & 1]);
+                // The multiply-adds are written out as v_pk_fma_f32 with the tap in the LOW dword of an aligned register pair and
+                // `op_sel_hi:[1,0,1]` (both results read src1's low dword).  hipcc's own choice for a tap that sits in the HIGH dword
+                // of a pair (the taps are consecutive registers: v[1] was the one) is `op_sel:[0,1,0]` -- the low result selects
+                // src1's high dword -- and THAT form intermittently drops its low-half product (D.lo = C.lo) in lanes 48..63 when the
+                // workgroup shares its CU with another kernel's waves: round 3's red split-sampler case (DESIGN.md section 2a;
+                // A/B of nothing but the operand selection, 600 concurrent forwards each: 0 vs 367 corrupted, every tap hit).
+                // tests/test_isa_audit_cpu.py fails the build if any shipped kernel carries a packed-fp32 op with an `op_sel:` bit set.
+                {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 tp = {v[i], v[i]};
 #pragma unroll
-                for (int q = 0; q < NQH; ++q) acc[q] += v[i] * wv[i & 1][q];
+                    for (int q = 0; q < NQH; ++q) {
+                        f32x2 a0 = {acc[q][0], acc[q][1]}, a1 = {acc[q][2], acc[q][3]};
+                        const f32x2 w0 = {wv[i & 1][q][0], wv[i & 1][q][1]}, w1 = {wv[i & 1][q][2], wv[i & 1][q][3]};
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a0) : "v"(w0), "v"(tp));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(a1) : "v"(w1), "v"(tp));
+                        acc[q] = (f32x4){a0[0], a0[1], a1[0], a1[1]};
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < NQH; ++q) asm volatile("" : "+v"(acc[q]));      // pinned: not sunk to the tile stores with all weights live
             }
 #pragma unroll
             for (int q = 0; q < NQH; ++q) *reinterpret_cast<f32x4*>(&tile[lane * PS + (h * NQH + q) * 4]) = acc[q];
         }
-#else
-        int wofs = 0;                                             // opaque per pass: otherwise all 18 * COUT weights are hoisted out of the
-        asm volatile("" : "+s"(wofs));                            // loop as loop invariants -- 864 SGPRs, spilled to VGPR lanes
-        const float* const wp = w + wofs;
-        f32x4 acc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = *reinterpret_cast<const f32x4*>(bias + q * 4);
-#if defined(PW_ABL) && PW_ABL == 7      // ablation: two taps instead of 18
-        for (int i = 0; i < 2; ++i) {
-#else
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {                            // i = ci * 9 + tap
-#endif
-            const float* wr = wp + ((i % 9) * 2 + i / 9) * COUT;  // uniform: scalar loads
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] += v[i] * *reinterpret_cast<const f32x4*>(wr + q * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(&tile[lane * PS + q * 4]) = acc[q];
-#endif
         // the wave's own patch: its LDS operations execute in order, no barrier
         const int npx = min(64, p1 - base);
 #pragma unroll
@@ -318,6 +309,16 @@ static hipError_t in_conv1_launch(const float* x, const float* cond, const float
     constexpr int SLOTS = BLOCKED ? 64 : 4 * (NQ / G64) * ((64 + NQ - 1) / NQ);
     static_assert(2 * COUT * SLOTS <= 4 * 64 * PS, "the statistics scratch aliases the tiles");
     const size_t lds = (size_t)4 * 64 * PS * sizeof(float) + (size_t)(COUT + 2) * STAT_WORDS * sizeof(stat_word) + 16 + (size_t)19 * COUT * sizeof(float);
+    if (lds > 64 * 1024) {                  // COUT = 64: 77.7 KB of dynamic LDS needs the limit raised, once per device
+        static bool raised[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!raised[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&in_conv1_kernel<COUT, BLOCKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            raised[dev] = true;
+        }
+    }
     hipLaunchKernelGGL((in_conv1_kernel<COUT, BLOCKED>), dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, H, W, per);
     return hipGetLastError();
 }

@@ -86,6 +86,12 @@ class UNetDiffusion(nn.Module):
         # stream): NaN / Inf activations or an operand beyond the split-fp16 range raise MiddError instead of returning garbage.
         # Set to False (env MIDD_CHECK_STATUS=0) to keep forward() / denoise() asynchronous; the output is NaN then, as torch's.
         self.check_status = bool(int(os.environ.get("MIDD_CHECK_STATUS", "1")))
+        # Debug / test knob (env MIDD_POISON_WS = a byte value 0..255, e.g. 255: every float reads as NaN, every statistics limb
+        # as -1): the workspace is filled with that byte before EVERY native call, so a kernel that reads scratch the call did
+        # not write first shows up as NaN / MiddError / a different answer instead of depending on what an earlier call with
+        # another layout left behind (the workspace is torch.empty and reused across programs of different layouts).
+        env_poison = os.environ.get("MIDD_POISON_WS")
+        self.poison_workspace: Optional[int] = int(env_poison) & 255 if env_poison not in (None, "") else None
 
     # ------------------------------------------------------------------ native plumbing
     @property
@@ -199,6 +205,8 @@ class UNetDiffusion(nn.Module):
             xc, cc = x.contiguous(), condition.contiguous()
             eps = torch.empty_like(xc)
             ws = self._workspace(B, H, W, x.device)
+            if self.poison_workspace is not None:
+                ws.fill_(self.poison_workspace)
             wptr, wbytes = self._aligned_ptr(ws)
             stream = torch.cuda.current_stream(x.device).cuda_stream
             native.check(native.lib().mi_unet_forward(
@@ -228,6 +236,8 @@ class UNetDiffusion(nn.Module):
                 step_noise = step_noise.to(torch.float32).contiguous()
                 nptr = step_noise.data_ptr()
             ws = self._workspace(B, H, W, noisy.device)
+            if self.poison_workspace is not None:
+                ws.fill_(self.poison_workspace)
             wptr, wbytes = self._aligned_ptr(ws)
             stream = torch.cuda.current_stream(noisy.device).cuda_stream
             fp = C.POINTER(C.c_float)

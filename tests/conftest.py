@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Every native call of the GPU suite starts from a workspace filled with 0xFF bytes (every float a NaN, every statistics limb -1):
+# a kernel that reads scratch the call did not write shows up as NaN / MiddError instead of depending on what an earlier call
+# with another layout left behind (modules.py reads the variable when a model is constructed).
+os.environ.setdefault("MIDD_POISON_WS", "255")
+
 import midd_loader  # noqa: E402
 
 midd_loader.load()

@@ -58,6 +58,7 @@ def test_config2_b8_256_50_iterations(full_model):
     noisy = torch.from_numpy(x).cuda()
     den = DiffusionDenoiser(model, noise_steps=50)
     out = den.denoise(noisy, inference_steps=50)
+    assert torch.equal(den.denoise(noisy, inference_steps=50), out), "the same two-stream call twice: identical bits (round 4)"
     d6, d1 = _maxdiff(out[6], g["den_out"][0]), _maxdiff(out[1], g["den_out"][0])
     print(f"config 2 (B=8, 256^2, 50 iterations, {model.compute}): max|d| slot 6 = {d6:.2e}, slot 1 = {d1:.2e}")
     assert d6 < TOL_FINAL and d1 < TOL_FINAL
@@ -292,6 +293,9 @@ def test_seeded_random_shapes_vs_oracle(compute):
             want_den = orc.denoise(sdt, topo, c, noise_steps=50, inference_steps=2)
         got = model(x.cuda(), c.cuda(), t.cuda())
         out = den.denoise(c.cuda(), inference_steps=2)
+        # (round 4) the same calls again: identical bits -- the statistics are order-free by construction (stats_common.h)
+        assert torch.equal(model(x.cuda(), c.cuda(), t.cuda()), got), f"case {case}: forward not repeatable"
+        assert torch.equal(den.denoise(c.cuda(), inference_steps=2), out), f"case {case}: B={B} {H}x{W}: sampler not repeatable"
         d, dd = _maxdiff(got, want), _maxdiff(out, want_den)
         worst = max(worst, d, dd)
         assert d < TOL_EPS * max(1.0, float(want.abs().max())) and dd < TOL_FINAL, f"case {case}: B={B} {H}x{W}: forward {d:.2e}, sampler {dd:.2e}"
