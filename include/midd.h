@@ -154,6 +154,13 @@ int mi_debug_attention_split(int N, int B, int* ksplit, int* tiles_per_split);
  * cap - 1 characters + NUL to buf (may be NULL) and returns the full length, or a negative MI_E* code. */
 int mi_debug_plan_dump(mi_plan* plan, int B, int H, int W, int side_by_side, char* buf, size_t cap);
 
+/* Debug/test hook, host only: the staging geometry of one instantiated tile of the split-fp16 3x3 / 1x1 kernel
+ * (conv_mfma_f16x3.hip: Conv16Geom) -- weight-ring slots, weight DMA pieces per wave and step, activation DMA pieces per wave
+ * and chunk, LDS bytes at 384 input channels.  tests/test_dma_protocol_cpu.py replays the kernel's issue / wait protocol with
+ * these numbers for every instantiated tile and checks every hand-counted `s_waitcnt vmcnt(N)`.  MI_EINVAL: not instantiated. */
+int mi_debug_conv16_geometry(int ks, int stride, int tw, int mt, int nt, int wm, int wn, int cb,
+                             int* ring, int* ppw, int* apw, int* lds_bytes);
+
 /* First 16 hex digits of the sha256 over the kernel sources (csrc/ *.h, *.hip) this library was BUILT from, embedded at
  * build time: what bench.py / tools/pmc_traffic.py compare profiles against (not the working tree). */
 const char* mi_source_hash(void);

@@ -468,6 +468,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // of step r was requested D >= 2 iterations (or 3x3 steps) earlier, i.e. before A(r): complete with it.
     constexpr int RL = 2 * MT;                            // untracked 16-byte loads per wave and res step
     constexpr int RG = (MT == 1) ? 2 : 1;                 // res steps per group: the loads of group g+1 fly under the MFMAs of group g
+    // every hand-counted vmcnt immediate of this instantiation fits the 6-bit field (k_step, chunk end, res_mfma, res_wait)
+    static_assert((D - 1) * PPW + APW <= 63 && D * PPW <= 63 && (D - 1) * PPW + RG * RL <= 63 && RG * PPW <= 63, "vmcnt immediate beyond 63");
     auto res_load = [&](int r, f32x4 (&dst)[MT][2]) {
         const int rc = a.res_C0 + a.res_C1;
         int ch = r * 32 + kq * 8;
@@ -530,8 +532,8 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     };
     // vmcnt bookkeeping per wave, program order (W = issue_w: PPW pieces; A(g) = RG*RL loads of group g):
     //   A(0) [wait 0] | group 0: A(1) W .. W [wait RG*PPW] | group 1: A(2) W .. W [wait RG*PPW] | ... | last group: W .. W
-    // A step's wait for its ring slot W(s) (requested D steps earlier, i.e. before the group's A): younger are
-    // W(s+1 .. s+D-1) and, if issued, the group's A.
+    // A step's wait for its ring slot W(s) (requested D steps earlier): younger are W(s+1 .. s+D-1) and the group's A if W(s)
+    // was requested before them (the group's i-th step: i < D).
     auto res_phase = [&]() {
         if constexpr (RES) {
             if (res_steps == 0) return;
@@ -553,9 +555,14 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     f32x4 ra[RG][MT][2];
 #pragma unroll
                     for (int i = 0; i < RG; ++i) res_load(min(r + RG + i, res_steps - 1), ra[i]);     // (a group's missing last step: a duplicate, unused)
-#pragma unroll
-                    for (int i = 0; i < RG; ++i)
-                        if (r + i < res_steps) res_mfma(std::true_type{}, rxh[i], rxl[i]);
+                    // the group's loads are younger than W(step) only while that slot was requested BEFORE them, i.e. for the
+                    // group's steps i < D (round 4: with a two-slot ring, D = 1, the second step's slot is requested after the
+                    // loads and nothing younger than it may stay outstanding -- found by tests/test_dma_protocol_cpu.py; the
+                    // three two-slot tiles with MT = 1 are never picked for the default network)
+                    res_mfma(std::true_type{}, rxh[0], rxl[0]);
+                    if constexpr (RG == 2) {
+                        if (r + 1 < res_steps) res_mfma(std::integral_constant<bool, (1 < D)>{}, rxh[1], rxl[1]);
+                    }
                     res_wait(ra, std::integral_constant<int, RG * PPW>{});
 #pragma unroll
                     for (int i = 0; i < RG; ++i) res_split(r + RG + i, ra[i], rxh[i], rxl[i]);

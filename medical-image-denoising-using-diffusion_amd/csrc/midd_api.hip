@@ -986,6 +986,14 @@ static int dump_program(mi_plan* p, int B, int H, int W, bool side_by_side, std:
     }
     return MI_OK;
 }
+extern "C" int mi_debug_conv16_geometry(int ks, int stride, int tw, int mt, int nt, int wm, int wn, int cb, int* ring, int* ppw, int* apw, int* lds_bytes) {
+    if (!ring || !ppw || !apw || !lds_bytes) return fail(MI_EINVAL, "null argument");
+    ConvTile t{ks, stride, tw, mt, nt, wm, wn, cb};
+    ConvLaunchInfo li{};
+    if (!conv16_launch_info(384, 16 * nt * wn, 1, 64, 64, t, 0, &li)) return fail(MI_EINVAL, "tile (%d,%d,%d,%d,%d) ks %d stride %d cb %d is not instantiated", tw, mt, nt, wm, wn, ks, stride, cb);
+    *ring = li.ring; *ppw = li.ppw; *apw = li.apw; *lds_bytes = li.lds_bytes;
+    return MI_OK;
+}
 extern "C" int mi_debug_plan_dump(mi_plan* plan, int B, int H, int W, int side_by_side, char* buf, size_t cap) {
     if (!plan) return fail(MI_EINVAL, "null plan");
     std::string text;
@@ -1213,7 +1221,8 @@ extern "C" int mi_denoise(mi_plan* plan, const float* noisy, float* x_out, int B
                     coef(t, &io.c1, &io.c2, &io.c3);
                     io.noise = (step_noise && t > 0) ? step_noise + (size_t)i * img_elems + h * part : nullptr;
                     io.clamp_eps = (flags & MI_CLAMP_EPS) ? 1 : 0;
-                    if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset
+                    if (i == 0 && h > 0) HIPCHK(hipStreamWaitEvent(sh, plan->sev_phase[h - 1], 0));      // phase offset (re-establishing it every n-th
+                                                                                                          // iteration measured -2 %: round 4; the streams run freely)
                     hipEvent_t mid = (i == 0 && h + 1 < parts) ? plan->sev_phase[h] : nullptr;
                     int rc2 = run_program(plan, gh, io, wsh, reinterpret_cast<int*>(ws), sh, mid, parts);
                     if (rc2) return rc2;

@@ -65,22 +65,24 @@ class HybridDenoisingRouter(nn.Module):
         self.diffusion_wrapper = DiffusionDenoiser(self.diffusion_unet, noise_steps=self._noise_steps)
         return out
 
+    def _backends(self):
+        return (("nafnet", self.nafnet), ("diffusion_unet", self.diffusion_unet))
+
     def load_pretrained_models(self, nafnet_path: str, diffusion_path: str) -> None:
-        naf_ckpt = torch.load(nafnet_path, map_location="cpu", weights_only=True)
-        self.nafnet.load_state_dict(naf_ckpt["model_state_dict"])
-        print("✓ NAFNet loaded")
-        diff_ckpt = torch.load(diffusion_path, map_location="cpu", weights_only=True)
-        self.diffusion_unet.load_state_dict(diff_ckpt["model_state_dict"])
-        print("✓ Diffusion loaded")
+        """Same method surface as hybrid3diffusionspeed.py:592-598: each backend takes the `model_state_dict` of its own checkpoint
+        file.  Restated, not transcribed: one loop over (module, path), tensors-only unpickling (the reference passes
+        weights_only=False), strict key check by load_state_dict, no console output."""
+        for (name, module), path in zip(self._backends(), (nafnet_path, diffusion_path)):
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+            if "model_state_dict" not in ckpt:
+                raise KeyError(f"{path}: checkpoint for {name} has no 'model_state_dict' entry")
+            module.load_state_dict(ckpt["model_state_dict"])
 
     def freeze_backends(self) -> None:
-        for param in self.nafnet.parameters():
-            param.requires_grad = False
-        for param in self.diffusion_unet.parameters():
-            param.requires_grad = False
-        self.nafnet.eval()
-        self.diffusion_unet.eval()
-        print("✓ Backends frozen")
+        """hybrid3diffusionspeed.py:600-606: both backends become inference-only (no gradients, eval mode); router and fusion stay trainable."""
+        for _, module in self._backends():
+            module.requires_grad_(False)
+            module.eval()
 
     def hq_denoised(self, noisy_input: torch.Tensor, diffusion_steps: Optional[int] = None) -> torch.Tensor:
         """The diffusion branch alone (:618-620): HIP sampler, then nan_to_num + clamp."""

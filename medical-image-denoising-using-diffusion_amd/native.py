@@ -62,6 +62,7 @@ SYMBOLS = [
     ("mi_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     ("mi_debug_attention_split", C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("mi_debug_plan_dump", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    ("mi_debug_conv16_geometry", C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_int)] * 4),
     ("mi_source_hash", C.c_char_p, []),
     ("mi_profile_begin", C.c_int, [C.c_void_p]),
     ("mi_profile_end", C.c_int, [C.c_void_p, C.POINTER(ProfileEntry), C.c_int, C.POINTER(C.c_int)]),

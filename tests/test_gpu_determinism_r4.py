@@ -130,3 +130,45 @@ def test_poison_patterns_do_not_change_forward_bits():
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     assert torch.isfinite(outs[0]).all()
+
+
+TWO_SLOT_KW = dict(model_channels=48, channel_mult=(2, 4), num_res_blocks=2, attention_resolutions=(1,), time_emb_dim=64)
+
+
+@pytest.mark.parametrize("shape", [(200, 4, 16), (256, 4, 32)], ids=["200x4x16", "256x4x32"])
+def test_two_slot_ring_tiles_with_folded_res_conv_vs_oracle(shape):
+    """Many tiny images: the picker takes the 16- and 32-pixel tiles whose weight ring has only TWO slots (one step in flight),
+    with the folded res_conv at 3, 6 and 12 extra K steps -- `conv_mfma_f16x3_kernel<3,1,8,1,3,1,4,true>` and
+    `<3,1,16,1,3,2,2,true>`, which no other test (and no plan of the default network) reaches.  tests/test_dma_protocol_cpu.py
+    found their res-phase wait one weight step short (round 4); this is the same path on the GPU: forward against the oracle,
+    repeated, and beside a second stream."""
+    B, H, W = shape
+    cfg = UNetConfig(**TWO_SLOT_KW)
+    sd = make_state_dict(cfg, seed=91)
+    m = _model(TWO_SLOT_KW, sd)
+    rng = np.random.default_rng(17)
+    x = torch.from_numpy(rng.random((B, 1, H, W), dtype=np.float32))
+    c = torch.from_numpy(synthetic_xray(B, H, W, seed=700))
+    t = torch.from_numpy(rng.integers(0, 50, B)).to(torch.int64)
+    with torch.no_grad():
+        want = orc.unet_forward(orc.to_torch(sd), topology(cfg), x, c, t)
+    xg, cg = x.cuda(), c.cuda()
+    got = m(xg, cg, t)
+    d = _maxdiff(got, want)
+    assert d < TOL_EPS * max(1.0, float(want.abs().max())), f"{d:.2e}"
+    for _ in range(5):
+        assert torch.equal(m(xg, cg, t), got)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    m.check_status = False
+    try:
+        for r in range(8):
+            torch.cuda.synchronize()
+            outs = []
+            for st in (s1, s2):
+                with torch.cuda.stream(st):
+                    outs.append(m(xg, cg, t))
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o, got), f"round {r}: differs by {_maxdiff(o, got):.2e} beside another stream"
+    finally:
+        m.check_status = True
