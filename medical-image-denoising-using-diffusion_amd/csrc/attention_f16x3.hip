@@ -339,13 +339,9 @@ hipError_t attention16_launch(const float* q, const _Float16* Kp, const _Float16
 #define MIDD_ATT(DD)                                                                                                        \
     {                                                                                                                       \
         constexpr int lds_bytes = 2 * Att16Geom<DD>::STAGE;                                                                 \
-        static bool raised = false;                                                                                         \
-        if (lds_bytes > 64 * 1024 && !raised) {                                                                             \
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x3_kernel<DD>),                             \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);                                 \
-            if (e != hipSuccess) return e;                                                                                  \
-            raised = true;                                                                                                  \
-        }                                                                                                                   \
+        static int raised[MIDD_MAX_DEVICES] = {};                                                                           \
+        e = ensure_dynamic_lds(reinterpret_cast<const void*>(&attention_f16x3_kernel<DD>), lds_bytes, raised);              \
+        if (e != hipSuccess) return e;                                                                                      \
         hipLaunchKernelGGL((attention_f16x3_kernel<DD>), dim3(qblocks * ksplit, heads, B), dim3(256), lds_bytes, s,         \
                            q, Kp, Vp, part_o, part_ml, N, Npad, C, qscale, ksplit, tps);                                    \
     }

@@ -373,14 +373,10 @@ static hipError_t launch1(const ConvArgs& a0, hipStream_t s) {
     a.wgs_per_img = conv16_wgs_per_img(a.tiles_x, a.B, ny, a.persist_wgs);
     const int lds_bytes = G::lds_bytes(a.C0 + a.C1, ATT);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-    if (lds_bytes > 64 * 1024) {
-        static int raised = 0;               // per instantiation
-        if (lds_bytes > raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_f16x3_kernel<MT, NT, ATT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            if (e != hipSuccess) return e;
-            raised = lds_bytes;
-        }
+    {
+        static int raised[MIDD_MAX_DEVICES] = {};          // per instantiation and device
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv1x1_f16x3_kernel<MT, NT, ATT>), lds_bytes, raised);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((conv1x1_f16x3_kernel<MT, NT, ATT>), dim3(a.B * a.wgs_per_img, ny), dim3(G::NTHREADS), lds_bytes, s, a);
     return hipGetLastError();

@@ -809,14 +809,10 @@ static hipError_t launch16(const ConvArgs& a0, hipStream_t s) {
     if constexpr (G::LDS_BYTES <= 160 * 1024 && (G::RING - 2) * G::PPW + G::APW <= 60) {
         const int lds_bytes = G::lds_bytes(a.C0 + a.C1);
         if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
-        if (lds_bytes > 64 * 1024) {
-            static int raised = 0;           // per instantiation
-            if (lds_bytes > raised) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES, CBT>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-                if (e != hipSuccess) return e;
-                raised = lds_bytes;
-            }
+        {
+            static int raised[MIDD_MAX_DEVICES] = {};      // per instantiation and device
+            hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES, CBT>), lds_bytes, raised);
+            if (e != hipSuccess) return e;
         }
         if ((double)a.H * a.W * 64.0 >= 4294967296.0) return hipErrorInvalidValue;  // 32-bit DMA offsets inside one block plane
         hipLaunchKernelGGL((conv_mfma_f16x3_kernel<KS, STRIDE, TW, MT, NT, WM, WN, RES, CBT>), grid, dim3(G::NTHREADS), lds_bytes, s, a);

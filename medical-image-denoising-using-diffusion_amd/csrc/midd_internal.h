@@ -17,6 +17,24 @@
 
 namespace midd {
 
+// Launches that ask for more than 64 KB of dynamic LDS must raise the kernel's limit first, once per (kernel instantiation,
+// device): `raised` is the instantiation's own static table, zero-initialised, indexed by device (the caches were per
+// process).  Returns hipSuccess when `bytes` is already allowed.
+constexpr int MIDD_MAX_DEVICES = 64;
+inline hipError_t ensure_dynamic_lds(const void* kernel, int bytes, int (&raised)[MIDD_MAX_DEVICES]) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= MIDD_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (bytes > raised[dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        raised[dev] = bytes;
+    }
+    return hipSuccess;
+}
+
 // ---------------------------------------------------------------- implicit-GEMM convolution
 enum Prologue { PRO_RAW = 0, PRO_GN = 1, PRO_GN_SILU = 2 };
 

@@ -309,15 +309,10 @@ static hipError_t in_conv1_launch(const float* x, const float* cond, const float
     constexpr int SLOTS = BLOCKED ? 64 : 4 * (NQ / G64) * ((64 + NQ - 1) / NQ);
     static_assert(2 * COUT * SLOTS <= 4 * 64 * PS, "the statistics scratch aliases the tiles");
     const size_t lds = (size_t)4 * 64 * PS * sizeof(float) + (size_t)(COUT + 2) * STAT_WORDS * sizeof(stat_word) + 16 + (size_t)19 * COUT * sizeof(float);
-    if (lds > 64 * 1024) {                  // COUT = 64: 77.7 KB of dynamic LDS needs the limit raised, once per device
-        static bool raised[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (!raised[dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&in_conv1_kernel<COUT, BLOCKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            raised[dev] = true;
-        }
+    {                                       // COUT = 64: 77.7 KB of dynamic LDS
+        static int raised[MIDD_MAX_DEVICES] = {};
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&in_conv1_kernel<COUT, BLOCKED>), (int)lds, raised);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((in_conv1_kernel<COUT, BLOCKED>), dim3(rows, B), dim3(256), lds, s, x, cond, w, bias, out, tot, rep, bs, H, W, per);
     return hipGetLastError();

@@ -84,13 +84,15 @@ def test_non_power_of_two_sizes_vs_oracle(shape, compute):
     x8 = torch.from_numpy(synthetic_xray(8, H, W, seed=31, kind="uniform"))
     c8 = torch.from_numpy(synthetic_xray(8, H, W, seed=32))
     t8 = torch.tensor([49, 3, 17, 0, 25, 40, 9, 33])
-    rows = [0, 2, 5]                       # the oracle is per-sample: three rows of the batch of 8 on the CPU (test time)
+    # the oracle is per-sample: three rows of the batch of 8 on the CPU (test time) -- and the WHOLE batch for the most ragged
+    # shape in the default arithmetic (keep one full-batch comparison on a ragged shape)
+    rows = list(range(8)) if (shape == (200, 184) and compute == "f16x3") else [0, 2, 5]
     with torch.no_grad():
         want = orc.unet_forward(sdt, topo, x8[rows], c8[rows], t8[rows])
     got8 = model(x8.cuda(), c8.cuda(), t8.cuda())
     got1 = model(x8[2:3].cuda(), c8[2:3].cuda(), t8[2:3].cuda())
     assert torch.isfinite(got8).all()
-    d8, d1 = _maxdiff(got8[rows], want), _maxdiff(got1, want[1:2])
+    d8, d1 = _maxdiff(got8[rows], want), _maxdiff(got1, want[rows.index(2):rows.index(2) + 1])
     print(f"{H}x{W} {compute}: forward max|d| B=8 {d8:.2e}, B=1 {d1:.2e}")
     assert d8 < TOL_EPS and d1 < TOL_EPS
     den = DiffusionDenoiser(model, noise_steps=50)
