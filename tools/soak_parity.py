@@ -82,6 +82,20 @@ def main():
         with torch.no_grad():
             want_den = orc.denoise(sdt, topo, c, noise_steps=50, inference_steps=2, step_noise=None if noise is None else [noise[0], noise[1]])
         dd = float((out.cpu() - want_den).abs().max())
+        # the same forward beside another stream's kernels: identical bits (round 4: the co-residency property)
+        xs, cs = x.cuda(), c.cuda()
+        m.check_status = False
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    o = m(xs, cs, t)
+                outs.append(o)
+        torch.cuda.synchronize()
+        m.check_status = True
+        rep = rep and all(torch.equal(o, got) for o in outs)
         ok = d < TOL_EPS and dd < TOL_FINAL and rep and torch.equal(out, out2)
         worst_f, worst_s = max(worst_f, d), max(worst_s, dd)
         done += 1
