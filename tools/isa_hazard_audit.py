@@ -4,7 +4,10 @@
    result selecting the HIGH dword of a source pair.  On MI355X that form intermittently drops its low-half product in lanes
    48..63 when the workgroup shares its CU with another kernel's waves (round 4, DESIGN.md section 2a: hipcc emitted it for
    one tap of in_conv1_kernel<32>; A/B of nothing but the operand selection: 0 vs 367 corrupted of 600 concurrent forwards).
-   `op_sel_hi` (the HIGH result selecting a LOW dword) is the form used everywhere else and is not affected.
+   `op_sel_hi` (the HIGH result selecting a LOW dword) is the form used everywhere else and is not affected.  The measured map
+   (tools/pk_opsel_map.py, profiles/r04_pk_opsel_map.txt): of the 96 (op, op_sel, op_sel_hi) combinations exactly those with
+   op_sel[0] = 0 and op_sel[1] = 1 fail beside fp16 MFMAs; the audit bans every op_sel bit, which is simpler and costs nothing
+   (hipcc reaches for op_sel only when a scalar operand happens to sit in the high half of an aligned pair).
 2. Encoded `s_waitcnt vmcnt(N)` immediates above 63 (6-bit field) -- the hand-counted LDS-DMA protocol.
 
 python tools/isa_hazard_audit.py file.s [...]   -> exit status 1 if anything is found."""
