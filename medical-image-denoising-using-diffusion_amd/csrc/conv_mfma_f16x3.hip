@@ -176,8 +176,33 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     const int lane16 = lane * 16;
     int wr_step = 0, wr_slot = 0;                         // next step to fetch / the ring slot it goes to
     const char* wr_src = wbase;                           // = wbase + wr_step * wstep_bytes, kept incrementally
+    // Diagnostic build (-DMIDD_DMA_CHECK, tools/dma_check.sh; never shipped): every destination of an asynchronous transfer -- ring
+    // slot pieces, landing-buffer slots, the registers of untracked loads -- is filled with a NaN sentinel before the transfer is
+    // requested, and every consumer checks what it reads: a counted wait that returns before its data has landed leaves the
+    // sentinel in place and sets STATUS_DMA_EARLY.  Run over the whole GPU suite this checks the hand-counted vmcnt protocol
+    // on the hardware, for every instantiation and schedule the tests reach.
+#ifdef MIDD_DMA_CHECK
+    constexpr unsigned SENT_W = 0x7FFF7FFFu;              // two fp16 NaNs: no packed weight
+    constexpr unsigned SENT_A = 0x7FC0DEADu;              // an fp32 NaN: no finite activation
+    unsigned dma_bad = 0;
+    auto sent4 = [](unsigned v) { typedef unsigned u32x4_ __attribute__((ext_vector_type(4))); return __builtin_bit_cast(f32x4, (u32x4_){v, v, v, v}); };
+    auto has_sent = [](const auto& q, unsigned v) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ u = __builtin_bit_cast(u32x4_, q);
+        return (unsigned)((u[0] == v) | (u[1] == v) | (u[2] == v) | (u[3] == v));
+    };
+#endif
     auto issue_w = [&]() {
         char* slot = wring + wr_slot * WSLICE;
+#ifdef MIDD_DMA_CHECK
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            int piece = (WM == 1) ? wave * PPW + i : wave + i * NW;
+            if (piece >= G::WPIECES) piece -= G::WPIECES;
+            lds_store_raw(slot + piece * 1024 + lane16, sent4(SENT_W));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             // WM == 1: every wave owns a distinct cout slice, so it fetches exactly the pieces it
@@ -223,6 +248,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         if ((blk << 4) < a.C0) { src = a.src0; bsrc = blk; nb = a.C0 >> 4; }
         else                   { src = a.src1; bsrc = blk - (a.C0 >> 4); nb = a.C1 >> 4; }
         const char* base = reinterpret_cast<const char*>(src) + ((size_t)(b * nb + bsrc) * (size_t)(a.H * a.W)) * 64 + (q8 & 3) * 16;
+#ifdef MIDD_DMA_CHECK
+#pragma unroll
+        for (int s = 0; s < APW; ++s) lds_store_raw(raw + (wave + s * NW) * 1024 + lane16, sent4(SENT_A));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
         for (int s = 0; s < APW; ++s) {
             const unsigned byte_off = (unsigned)max(g_off[s], 0) * 64u;             // one block plane is < 4 GiB (host-checked)
@@ -254,6 +284,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         f32x4 rq[APW];
 #pragma unroll
         for (int s = 0; s < APW; ++s) rq[s] = *reinterpret_cast<const f32x4*>(raw + (tid + s * NTHREADS) * 16);
+#ifdef MIDD_DMA_CHECK
+#pragma unroll
+        for (int s = 0; s < APW; ++s) dma_bad |= has_sent(rq[s], SENT_A);
+#endif
         f32x4 sc = {rscale, rscale, rscale, rscale}, sh = {0.f, 0.f, 0.f, 0.f};      // raw operand: per-sample 2^a (stats_common.h)
         if (a.prologue != PRO_RAW) {
             sc = *reinterpret_cast<const f32x4*>(gnp + ch);
@@ -406,6 +440,10 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             wh[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048);
             wl[nt] = *reinterpret_cast<const half8*>(wslot + nt * 2048 + 1024);
         }
+#ifdef MIDD_DMA_CHECK
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dma_bad |= has_sent(wh[nt], SENT_W) | has_sent(wl[nt], SENT_W);
+#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -431,7 +469,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     // image, so the fragments are read after it (WM == 1 has a dedicated barrier after the transform).
     auto k_step = [&](auto with_a, bool first, bool first_with_more, int next_chunk, const int (&xo)[MT]) {
         constexpr bool WITH_A = decltype(with_a)::value;
+#ifdef MIDD_DMA_CHECK_BREAK                // the checker's own test: a wait that is one weight step too permissive must be reported
+        constexpr int N = D * PPW + (WITH_A ? APW : 0);
+#else
         constexpr int N = (D - 1) * PPW + (WITH_A ? APW : 0);
+#endif
         const bool early = (WM == 1) || !first;
         if (early) {
             load_x(xo);
@@ -483,8 +525,14 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
             const int py = pp / TW, px = pp - py * TW;
             const int oy = min(oy0 + py, a.OH - 1), ox = min(ox0 + px, a.OW - 1);
             const float* q = src + (size_t)(oy * a.OW + ox) * 16;
+#ifdef MIDD_DMA_CHECK
+            dst[mt][0] = sent4(SENT_A); dst[mt][1] = sent4(SENT_A);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(dst[mt][0]) : "v"(q) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "+v"(dst[mt][1]) : "v"(q) : "memory");
+#else
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst[mt][0]) : "v"(q) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=&v"(dst[mt][1]) : "v"(q) : "memory");
+#endif
         }
     };
     // The raw registers of a group are written by the load statements and named again ("+v") by ONE wait statement: no
@@ -503,6 +551,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
         const bool valid = r * 32 + kq * 8 < a.res_C0 + a.res_C1;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+#ifdef MIDD_DMA_CHECK
+            dma_bad |= has_sent(ra[mt][0], SENT_A) | has_sent(ra[mt][1], SENT_A);
+#endif
             f32x4 v0 = ra[mt][0] * res_in, v1 = ra[mt][1] * res_in;
             if (!valid) { v0 = (f32x4){0.f, 0.f, 0.f, 0.f}; v1 = v0; }        // keep the dummy finite
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -608,8 +659,14 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)       // (rows beyond the image: a valid, clamped address; never stored)
+                for (int nt = 0; nt < NT; ++nt) {     // (rows beyond the image: a valid, clamped address; never stored)
+#ifdef MIDD_DMA_CHECK
+                    rres[mt][nt] = sent4(SENT_A);
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(rres[mt][nt]) : "v"(a.resid + obase[mt] + nt * ohw * 16) : "memory");
+#else
                     asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rres[mt][nt]) : "v"(a.resid + obase[mt] + nt * ohw * 16) : "memory");
+#endif
+                }
             // one statement names every destination: nothing that uses (or copies) them can be scheduled above the wait
             if constexpr (MT == 2 && NT == 3) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[0][2]), "+v"(rres[1][0]), "+v"(rres[1][1]), "+v"(rres[1][2]) :: "memory");
             else if constexpr (MT == 2 && NT == 2) asm volatile("s_waitcnt vmcnt(0) ; asm-loads-landed" : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[1][0]), "+v"(rres[1][1]) :: "memory");
@@ -625,6 +682,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                 for (int nt = 0; nt < NT; ++nt) {
                     const f32x4 add = *reinterpret_cast<const f32x4*>(add_lds + (wn * NT + nt) * 16 + kq * 4);
                     f32x4 v = acc[mt][nt] * oscale + add;
+#ifdef MIDD_DMA_CHECK
+                    if (a.resid != nullptr) dma_bad |= has_sent(rres[mt][nt], SENT_A);
+#endif
                     if (a.resid != nullptr) v += rres[mt][nt];
                     *reinterpret_cast<f32x4*>(a.out + obase[mt] + nt * ohw * 16) = v;
 #if !(defined(C16_ABL) && C16_ABL == 1)  // ablation 1 (wrong results): no statistics of the output
@@ -755,6 +815,9 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
     epilogue();
     TS(TS_EPILOGUE)
     publish_stats();
+#ifdef MIDD_DMA_CHECK
+    if (dma_bad && a.status != nullptr) atomicOr(a.status, (int)STATUS_DMA_EARLY);
+#endif
     TS(TS_PUBLISH)
 #ifdef MIDD_CONV_TIMING
     if (tid == 0) {

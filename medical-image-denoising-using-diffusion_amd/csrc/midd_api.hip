@@ -1260,6 +1260,9 @@ extern "C" int mi_status(const void* workspace, void* stream, int* flags) {
     HIPCHK(hipMemcpyAsync(&host, workspace, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     *flags = host;
+    // diagnostic builds (-DMIDD_DMA_CHECK): the NaN sentinel of a transfer that had not landed also sets the other two bits
+    if (host & ~(MI_STATUS_NONFINITE | MI_STATUS_FP16_RANGE))
+        return fail(MI_ERANGE, "status word 0x%x (bit 4: a -DMIDD_DMA_CHECK build saw an operand that had not landed when its counted wait returned)", host);
     // the range flag first: an operand beyond fp16 turns into Inf / NaN downstream, so both bits are usually set then
     if (host & MI_STATUS_FP16_RANGE)
         return fail(MI_ERANGE, "an attention operand exceeds the split-fp16 range (|q|, |k| or |v| >= 4094, or not finite): use compute=\"f32\"%s",

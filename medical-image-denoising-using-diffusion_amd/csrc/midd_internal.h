@@ -109,7 +109,8 @@ struct ConvTile {           // which template instance to launch
 
 enum ComputeMode { MODE_F32 = 0, MODE_F16X3 = 1 };
 enum AttMode { ATT_NONE = 0, ATT_QKV_OUT = 1, ATT_PART_IN = 2 };
-enum StatusBits { STATUS_NONFINITE = 1, STATUS_FP16_RANGE = 2 };      // == MI_STATUS_* (include/midd.h)
+enum StatusBits { STATUS_NONFINITE = 1, STATUS_FP16_RANGE = 2,          // == MI_STATUS_* (include/midd.h)
+                  STATUS_DMA_EARLY = 4 };      // diagnostic builds only (-DMIDD_DMA_CHECK, tools/dma_check.sh): data used before its counted wait had covered it
 
 // Picks a tile for (Cout, output pixels, kernel size, stride); returns false if unsupported.
 bool conv_pick_tile(int Cout, int B, int OH, int OW, int ks, int stride, ConvTile* t);
