@@ -612,7 +612,11 @@ void conv_mfma_f16x3_kernel(const ConvArgs a) {
                     // three two-slot tiles with MT = 1 are never picked for the default network)
                     res_mfma(std::true_type{}, rxh[0], rxl[0]);
                     if constexpr (RG == 2) {
+#ifdef MIDD_DMA_CHECK_OLD_RES              // the checker's second self-test: round 3's count for this step (the loads counted although they are older)
+                        if (r + 1 < res_steps) res_mfma(std::true_type{}, rxh[1], rxl[1]);
+#else
                         if (r + 1 < res_steps) res_mfma(std::integral_constant<bool, (1 < D)>{}, rxh[1], rxl[1]);
+#endif
                     }
                     res_wait(ra, std::integral_constant<int, RG * PPW>{});
 #pragma unroll
