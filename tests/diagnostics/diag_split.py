@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import midd_loader
 midd_loader.load()
 from midd_amd import UNetDiffusion, DiffusionDenoiser, UNetConfig, topology, timestep_list, native

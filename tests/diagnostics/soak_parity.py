@@ -1,6 +1,6 @@
 """Randomised parity soak (GPU box, one-off; not part of the test suite): random reference-valid topologies x batch x image size x
 variant x arithmetic, forward (per-sample t) and a 2-iteration sampler against the CPU oracle, every call twice (identical bits).
-Explores planner / tile-picker / key-split paths the fixed tests do not name.  python tools/soak_parity.py [cases] [seed]"""
+Explores planner / tile-picker / key-split paths the fixed tests do not name.  python tests/diagnostics/soak_parity.py [cases] [seed]"""
 import os
 import sys
 import time
@@ -9,7 +9,7 @@ os.environ.setdefault("MIDD_POISON_WS", "255")
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import midd_loader
 midd_loader.load()
 from midd_amd import UNetDiffusion, DiffusionDenoiser, UNetConfig, topology, native
