@@ -35,8 +35,18 @@ def isa_dumps(tmp_path_factory):
                        check=True, capture_output=True, timeout=1200)
         return src, out
 
+    def diagnostic_build():
+        # the DMA-checking build of the 3x3 kernel (tools/dma_check.sh) must keep compiling, self-tests included
+        out = os.path.join(str(out_dir), "conv_mfma_f16x3.dmacheck.s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-DMIDD_DMA_CHECK", "-DMIDD_DMA_CHECK_BREAK",
+                        "-DMIDD_DMA_CHECK_OLD_RES", os.path.join(CSRC, "conv_mfma_f16x3.hip"), "-o", out], check=True, capture_output=True, timeout=1200)
+        return "conv_mfma_f16x3.hip:dmacheck", out
+
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        return dict(ex.map(one, SOURCES))
+        extra = ex.submit(diagnostic_build)
+        dumps = dict(ex.map(one, SOURCES))
+        dumps.update([extra.result()])
+        return dumps
 
 
 def test_every_translation_unit_is_audited():
@@ -64,3 +74,9 @@ def test_the_audit_catches_the_form(tmp_path):
                  "\tv_pk_fma_f32 v[56:57], v[106:107], v[34:35], v[56:57] op_sel_hi:[1,0,1]\n\ts_waitcnt vmcnt(64)\n")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hazard_audit.py"), str(p)], capture_output=True, text=True)
     assert r.returncode == 1 and "2 finding(s)" in r.stdout, r.stdout
+
+
+def test_dma_checking_build_compiles_and_checks(isa_dumps):
+    """tools/dma_check.sh's diagnostic build: it compiles, and it really contains the sentinel stores and comparisons."""
+    text = open(isa_dumps["conv_mfma_f16x3.hip:dmacheck"]).read()
+    assert text.count("0x7fff7fff") > 50 and text.count("0x7fc0dead") > 50
